@@ -1,0 +1,100 @@
+"""ctypes binding of the CPU oracle (oracle/pairhmm_oracle.c) — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; the product package gatk_amd never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libpairhmm_oracle.so")
+
+EXACT, ORIGINAL, LOGLESS = 0, 1, 2  # HMM_IMPLEMENTATION EXACT / ORIGINAL / LOGLESS_CACHING
+OK, ILLEGAL_ARGUMENT, ILLEGAL_STATE, INDEX_OUT_OF_BOUNDS = 0, 1, 2, 3
+
+_lib = None
+
+
+def build():
+    """Compile the oracle with the Makefile beside it."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        u8p, i32p, f64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        L.oracle_init.restype = None
+        L.oracle_computeLikelihoods.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, u8p, u8p, u8p, i32p, u8p, i32p, f64p]
+        L.oracle_computeLikelihoods.restype = C.c_int
+        L.oracle_logless_batch_fast.argtypes = [C.c_int, C.c_int, u8p, u8p, u8p, u8p, u8p, i32p, u8p, i32p, f64p, C.c_int]
+        L.oracle_logless_batch_fast.restype = C.c_int
+        for name, at in [("oracle_qualToErrorProb", [C.c_uint8]), ("oracle_qualToProb", [C.c_uint8]),
+                         ("oracle_qualToProbLog10", [C.c_uint8]), ("oracle_qualToErrorProbLog10", [C.c_uint8]),
+                         ("oracle_qualToErrorProb_d", [C.c_double]),
+                         ("oracle_approximateLog10SumLog10_2", [C.c_double, C.c_double]),
+                         ("oracle_approximateLog10SumLog10_3", [C.c_double, C.c_double, C.c_double]),
+                         ("oracle_approximateLog10SumLog10_arr", [f64p, C.c_int]),
+                         ("oracle_log10sumLog10", [f64p, C.c_int, C.c_int]),
+                         ("oracle_matchToMatchProb", [C.c_int, C.c_int]),
+                         ("oracle_matchToMatchProbLog10", [C.c_int, C.c_int]),
+                         ("oracle_jacobian_entry", [C.c_int]), ("oracle_mm_table_entry", [C.c_int, C.c_int])]:
+            f = getattr(L, name)
+            f.argtypes = at
+            f.restype = C.c_double
+        L.oracle_goodLog10Probability.argtypes = [C.c_double]
+        L.oracle_goodLog10Probability.restype = C.c_int
+        L.oracle_jacobian_table_size.restype = C.c_int
+        L.oracle_qualToTransProbs.argtypes = [f64p, C.c_uint8, C.c_uint8, C.c_uint8]
+        L.oracle_qualToTransProbs.restype = C.c_int
+        L.oracle_qualToTransProbsLog10.argtypes = [f64p, C.c_uint8, C.c_uint8, C.c_uint8]
+        L.oracle_qualToTransProbsLog10.restype = C.c_int
+        L.oracle_init()
+        _lib = L
+    return _lib
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def arr_fn(name, vals, *extra):
+    v = np.ascontiguousarray(vals, dtype=np.float64)
+    return getattr(lib(), name)(v.ctypes.data_as(C.POINTER(C.c_double)), *extra)
+
+
+def trans_probs(ins, dele, gcp, log10=False):
+    out = np.zeros(6, dtype=np.float64)
+    f = lib().oracle_qualToTransProbsLog10 if log10 else lib().oracle_qualToTransProbs
+    rc = f(out.ctypes.data_as(C.POINTER(C.c_double)), ins, dele, gcp)
+    return rc, out
+
+
+def compute_likelihoods(batch, mode=LOGLESS, fast_threads=0):
+    """Run PairHMM.computeLikelihoods on a packed batch (gatk_amd.batch.Batch-like object with
+    read_bases/read_quals/ins_gop/del_gop/gcp/read_offsets/hap_bases/hap_offsets numpy arrays).
+    Returns (rc, out[numReads, numHaps])."""
+    nr, nh = len(batch.read_offsets) - 1, len(batch.hap_offsets) - 1
+    out = np.full((nr, nh), np.nan, dtype=np.float64)
+    keep = [_u8(batch.read_bases), _u8(batch.read_quals), _u8(batch.ins_gop), _u8(batch.del_gop), _u8(batch.gcp),
+            _i32(batch.read_offsets), _u8(batch.hap_bases), _i32(batch.hap_offsets)]
+    p = [k[1] for k in keep]
+    op = out.ctypes.data_as(C.POINTER(C.c_double))
+    if fast_threads > 0:
+        assert mode == LOGLESS
+        rc = lib().oracle_logless_batch_fast(nr, nh, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], op, fast_threads)
+    else:
+        rc = lib().oracle_computeLikelihoods(mode, nr, nh, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], op)
+    return rc, out
