@@ -1,0 +1,758 @@
+// C-ABI of the PairHMM engine (include/gatk_pairhmm.h): argument checks with the reference's
+// error behaviour, the host-side planner that turns region batches into wavefront tasks, device
+// buffer management and kernel sequencing.  There is no CPU compute path in this file: every
+// likelihood comes out of the HIP kernels, and handle creation fails when no device is present.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/gatk_pairhmm.h"
+#include "pairhmm_device.h"
+#include "pairhmm_tables.h"
+
+namespace pairhmm_hip {
+hipError_t launch_forward(const DeviceBatch& B, int rows_per_lane, bool hap_has_n, bool fp64, bool list_mode,
+                          int blocks, hipStream_t stream);
+hipError_t launch_validate(const DeviceBatch& B, hipStream_t stream);
+hipError_t launch_fill_neg_inf(double* out, const int32_t* idx, int n, hipStream_t stream);
+}  // namespace pairhmm_hip
+
+using namespace pairhmm_hip;
+
+namespace {
+
+thread_local std::string g_last_error;
+std::atomic<int> g_num_threads{1};
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? GATK_PAIRHMM_OUT_OF_MEMORY : GATK_PAIRHMM_DEVICE_ERROR, \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                             \
+    } while (0)
+
+// Grow-only device buffer.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr; cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct Bucket {
+    int rows_per_lane = 0;
+    int task_begin = 0;  // offset into the task array
+    int num_tasks = 0;
+    int lds_per_wave = 0;
+    bool hap_has_n = false;
+};
+
+}  // namespace
+
+struct gatk_pairhmm_resident {
+    // ---- host-side plan ----
+    int num_regions = 0;
+    std::vector<int64_t> region_out_off;  // [num_regions + 1] offsets into the concatenated output
+    int64_t total_pairs = 0, cells = 0;
+    int64_t total_read_bytes = 0;
+    int num_reads = 0, num_haps = 0, num_groups = 0;
+    std::vector<Bucket> buckets;
+    std::vector<Task> tasks;
+    std::vector<int32_t> group_segs;   // reads packed in each group
+    std::vector<int32_t> neg_inf_idx;  // output slots of zero-length reads
+    bool computed = false;
+    // ---- device ----
+    DevBuf d_read_bases, d_read_quals, d_ins, d_del, d_gcp, d_read_off, d_read_out_base;
+    DevBuf d_hap_pool, d_hap_off, d_hap_len, d_hap_local, d_lanes, d_group_fill, d_tasks;
+    DevBuf d_out, d_rerun_lists, d_counters, d_neg_inf_idx;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    void release() {
+        for (DevBuf* b : {&d_read_bases, &d_read_quals, &d_ins, &d_del, &d_gcp, &d_read_off, &d_read_out_base, &d_hap_pool,
+                          &d_hap_off, &d_hap_len, &d_hap_local, &d_lanes, &d_group_fill, &d_tasks, &d_out, &d_rerun_lists,
+                          &d_counters, &d_neg_inf_idx})
+            b->release();
+        for (auto& e : ev)
+            if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    }
+};
+
+struct gatk_pairhmm {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    double* d_err = nullptr;
+    double* d_mm = nullptr;
+    bool initialized = false;
+    int max_read = 0, max_hap = 0;
+    float fp32_threshold = 1e-28f;
+    int force_rows_per_lane = 0;
+    bool force_fp64 = false;
+    bool timing = false;
+    gatk_pairhmm_resident scratch;  // buffers reused by the host-pointer entry points
+    std::vector<double> likelihood_array;
+    gatk_pairhmm_stats stats{};
+    // BatchPairHMM queue: one single-read region per batchAdd
+    struct Queued {
+        std::vector<uint8_t> bases, quals, ins, del, gcp, haps;
+        std::vector<int32_t> hap_off;
+    };
+    std::vector<Queued> queue;
+    std::vector<double> queue_results;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Planner
+// ---------------------------------------------------------------------------------------------
+
+// Rows per lane for a region: minimise modelled issue slots, keeping enough waves in flight.
+int choose_rows_per_lane(int max_read_len, int64_t num_reads, int64_t num_haps, double mean_hap_len, int forced) {
+    const int min_k = (max_read_len + kWave - 1) / kWave;
+    if (forced >= min_k && forced <= kMaxRowsPerLane) return forced;
+    int best_k = std::max(min_k, 1);
+    double best = std::numeric_limits<double>::infinity();
+    for (int k = std::max(min_k, 1); k <= kMaxRowsPerLane; ++k) {
+        const int lanes = (max_read_len + k - 1) / k;
+        const int per_wave = std::max(1, kWave / lanes);
+        const double tasks = std::ceil(static_cast<double>(num_reads) / per_wave) * static_cast<double>(num_haps);
+        const double steps = mean_hap_len + lanes - 1;
+        const double slots = steps * (10.0 * k + 10.0);          // VALU instructions per task
+        const double in_flight = std::min(tasks, 2048.0);        // 2 waves on each of 1024 SIMDs saturate issue
+        const double t = tasks * slots / in_flight;
+        if (t < best * 0.98) { best = t; best_k = k; }
+    }
+    return best_k;
+}
+
+int check_region(const gatk_pairhmm_batch& b, int k) {
+    char where[64];
+    snprintf(where, sizeof where, " (region %d)", k);
+    if (b.num_reads < 0 || b.num_haps < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("negative read or haplotype count") + where);
+    if (b.num_reads == 0) return GATK_PAIRHMM_OK;  // PairHMM.java:193
+    if (!b.read_offsets || !b.read_bases || !b.read_quals || !b.ins_gop || !b.del_gop || !b.gcp)
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("readBases cannot be null") + where);
+    int read_max = 0, hap_max = 0;
+    for (int r = 0; r < b.num_reads; ++r) {
+        const int len = b.read_offsets[r + 1] - b.read_offsets[r];
+        if (len < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("read offsets must not decrease") + where);
+        read_max = std::max(read_max, len);
+    }
+    if (b.num_haps > 0 && (!b.hap_offsets || !b.hap_bases))
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("haplotypeBases cannot be null") + where);
+    for (int a = 0; a < b.num_haps; ++a) {
+        const int len = b.hap_offsets[a + 1] - b.hap_offsets[a];
+        if (len < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("haplotype offsets must not decrease") + where);
+        hap_max = std::max(hap_max, len);
+    }
+    // PairHMM.initialize, reached through PairHMM.java:200-201
+    if (read_max <= 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "READ_MAX_LENGTH must be > 0 but got " + std::to_string(read_max) + where);
+    if (hap_max <= 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "HAPLOTYPE_MAX_LENGTH must be > 0 but got " + std::to_string(hap_max) + where);
+    for (int a = 0; a < b.num_haps; ++a)
+        if (b.hap_offsets[a + 1] - b.hap_offsets[a] == 0)
+            return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("zero-length haplotype: the reference result is undefined") + where);
+    if (read_max > kWave * kMaxRowsPerLane)
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "readBases is too long, got " + std::to_string(read_max) + " but max is " +
+                                                       std::to_string(kWave * kMaxRowsPerLane) + where);
+    return GATK_PAIRHMM_OK;
+}
+
+template <typename T>
+int upload_vec(DevBuf& buf, const std::vector<T>& v, hipStream_t s) {
+    HIP_TRY(buf.ensure(std::max<size_t>(v.size() * sizeof(T), 16)));
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return GATK_PAIRHMM_OK;
+}
+
+int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, const gatk_pairhmm_batch* regions) {
+    if (num_regions < 0 || (num_regions > 0 && !regions)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "regions cannot be null");
+    for (int k = 0; k < num_regions; ++k)
+        if (int rc = check_region(regions[k], k)) return rc;
+
+    R->num_regions = num_regions;
+    R->region_out_off.assign(num_regions + 1, 0);
+    R->buckets.clear(); R->tasks.clear(); R->group_segs.clear(); R->neg_inf_idx.clear();
+    R->computed = false;
+
+    std::vector<uint8_t> rb, rq, ri, rd, rg, hap_pool;
+    std::vector<int32_t> read_off{0}, read_out_base, hap_off, hap_len, hap_local, group_fill;
+    std::vector<LaneDesc> lanes;
+    std::vector<std::vector<Task>> tasks_by_k(kMaxRowsPerLane + 1);
+    std::vector<int> lds_by_k(kMaxRowsPerLane + 1, 0);
+    bool any_hap_n = false;
+    int64_t cells = 0, pairs = 0;
+    int read_max_all = 0, hap_max_all = 0;
+
+    for (int k = 0; k < num_regions; ++k) {
+        const gatk_pairhmm_batch& b = regions[k];
+        const int nr = b.num_reads, nh = b.num_reads == 0 ? 0 : b.num_haps;
+        R->region_out_off[k + 1] = R->region_out_off[k] + static_cast<int64_t>(nr) * nh;
+        if (nr == 0 || nh == 0) continue;
+        if (R->region_out_off[k + 1] >= (int64_t{1} << 31)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "more than 2^31 pairs in one call");
+        // haplotypes
+        const int hap_base_idx = static_cast<int>(hap_len.size());
+        int64_t hap_total = 0;
+        int hap_max = 0;
+        for (int a = 0; a < nh; ++a) {
+            const int o = b.hap_offsets[a], len = b.hap_offsets[a + 1] - o;
+            hap_off.push_back(static_cast<int32_t>(hap_pool.size()));
+            hap_len.push_back(len);
+            hap_local.push_back(a);
+            hap_pool.insert(hap_pool.end(), b.hap_bases + o, b.hap_bases + o + len);
+            hap_pool.resize((hap_pool.size() + 15) & ~size_t{15}, 0);
+            if (!any_hap_n && memchr(b.hap_bases + o, 'N', len)) any_hap_n = true;
+            hap_total += len;
+            hap_max = std::max(hap_max, len);
+        }
+        hap_max_all = std::max(hap_max_all, hap_max);
+        // reads
+        const int read_base_idx = static_cast<int>(read_out_base.size());
+        const int bo = b.read_offsets[0];
+        const int total = b.read_offsets[nr] - bo;
+        const int32_t byte_base = read_off.back();
+        rb.insert(rb.end(), b.read_bases + bo, b.read_bases + bo + total);
+        rq.insert(rq.end(), b.read_quals + bo, b.read_quals + bo + total);
+        ri.insert(ri.end(), b.ins_gop + bo, b.ins_gop + bo + total);
+        rd.insert(rd.end(), b.del_gop + bo, b.del_gop + bo + total);
+        rg.insert(rg.end(), b.gcp + bo, b.gcp + bo + total);
+        std::vector<int> order;
+        order.reserve(nr);
+        int read_max = 0;
+        for (int r = 0; r < nr; ++r) {
+            const int len = b.read_offsets[r + 1] - b.read_offsets[r];
+            read_off.push_back(byte_base + (b.read_offsets[r + 1] - bo));
+            read_out_base.push_back(static_cast<int32_t>(R->region_out_off[k] + static_cast<int64_t>(r) * nh));
+            read_max = std::max(read_max, len);
+            cells += static_cast<int64_t>(len) * hap_total;
+            if (len > 0) order.push_back(r);
+            else  // a zero-length read sums an empty last row: log10(0) (Log10PairHMM.java:128-134 on row 0)
+                for (int a = 0; a < nh; ++a) R->neg_inf_idx.push_back(read_out_base.back() + a);
+        }
+        read_max_all = std::max(read_max_all, read_max);
+        pairs += static_cast<int64_t>(nr) * nh;
+        // wave-groups: longest reads first, first-fit into 64 lanes
+        const int K = choose_rows_per_lane(read_max, nr, nh, static_cast<double>(hap_total) / nh, h->force_rows_per_lane);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+            return (b.read_offsets[x + 1] - b.read_offsets[x]) > (b.read_offsets[y + 1] - b.read_offsets[y]);
+        });
+        const int first_group = static_cast<int>(group_fill.size());
+        size_t pos = 0;
+        while (pos < order.size()) {
+            const size_t lane_base = lanes.size();
+            lanes.resize(lane_base + kWave, LaneDesc{-1, 1, 0, 0});
+            int used = 0, max_seg = 0, segs = 0;
+            while (pos < order.size()) {
+                const int r = order[pos];
+                const int len = b.read_offsets[r + 1] - b.read_offsets[r];
+                const int seg = (len + K - 1) / K;
+                if (used + seg > kWave) break;
+                const int pad_top = seg * K - len;
+                for (int t = 0; t < seg; ++t) {
+                    LaneDesc& ld = lanes[lane_base + used + t];
+                    ld.read_idx = read_base_idx + r;
+                    ld.first_row = t * K + 1 - pad_top;
+                    ld.seg_lane = t;
+                    ld.seg_last = (t == seg - 1) ? 1 : 0;
+                }
+                used += seg;
+                max_seg = std::max(max_seg, seg);
+                ++segs; ++pos;
+            }
+            group_fill.push_back(max_seg - 1);
+            R->group_segs.push_back(segs);
+        }
+        const int last_group = static_cast<int>(group_fill.size());
+        for (int a = 0; a < nh; ++a)
+            for (int g = first_group; g < last_group; ++g) tasks_by_k[K].push_back(Task{g, hap_base_idx + a});
+        const int lds = (kHapFrontPad + ((hap_max + 3) & ~3) + kWave + 8 + 15) & ~15;
+        lds_by_k[K] = std::max(lds_by_k[K], lds);
+    }
+    if (hap_max_all > 16000) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "Haplotype bases is too long, got " + std::to_string(hap_max_all) + " but max is 16000");
+
+    // PairHMM.java:200-201: grow the instance's maxima when a batch exceeds them
+    if (pairs > 0 && (!h->initialized || read_max_all > h->max_read || hap_max_all > h->max_hap)) {
+        h->max_read = std::max(h->max_read, read_max_all);
+        h->max_hap = std::max(h->max_hap, hap_max_all);
+        h->initialized = true;
+    }
+
+    // longest tasks first inside each bucket, so the tail of a launch is made of short tasks
+    for (int K = 1; K <= kMaxRowsPerLane; ++K) {
+        auto& tv = tasks_by_k[K];
+        if (tv.empty()) continue;
+        std::stable_sort(tv.begin(), tv.end(), [&](const Task& x, const Task& y) {
+            return hap_len[x.hap] + group_fill[x.group] > hap_len[y.hap] + group_fill[y.group];
+        });
+        Bucket bk;
+        bk.rows_per_lane = K;
+        bk.task_begin = static_cast<int>(R->tasks.size());
+        bk.num_tasks = static_cast<int>(tv.size());
+        bk.lds_per_wave = lds_by_k[K];
+        bk.hap_has_n = any_hap_n;
+        R->tasks.insert(R->tasks.end(), tv.begin(), tv.end());
+        R->buckets.push_back(bk);
+    }
+    R->total_pairs = pairs;
+    R->cells = cells;
+    R->total_read_bytes = static_cast<int64_t>(rb.size());
+    R->num_reads = static_cast<int>(read_out_base.size());
+    R->num_haps = static_cast<int>(hap_len.size());
+    R->num_groups = static_cast<int>(group_fill.size());
+
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    hap_pool.resize(hap_pool.size() + 16, 0);
+    if (int rc = upload_vec(R->d_read_bases, rb, s)) return rc;
+    if (int rc = upload_vec(R->d_read_quals, rq, s)) return rc;
+    if (int rc = upload_vec(R->d_ins, ri, s)) return rc;
+    if (int rc = upload_vec(R->d_del, rd, s)) return rc;
+    if (int rc = upload_vec(R->d_gcp, rg, s)) return rc;
+    if (int rc = upload_vec(R->d_read_off, read_off, s)) return rc;
+    if (int rc = upload_vec(R->d_read_out_base, read_out_base, s)) return rc;
+    if (int rc = upload_vec(R->d_hap_pool, hap_pool, s)) return rc;
+    if (int rc = upload_vec(R->d_hap_off, hap_off, s)) return rc;
+    if (int rc = upload_vec(R->d_hap_len, hap_len, s)) return rc;
+    if (int rc = upload_vec(R->d_hap_local, hap_local, s)) return rc;
+    if (int rc = upload_vec(R->d_lanes, lanes, s)) return rc;
+    if (int rc = upload_vec(R->d_group_fill, group_fill, s)) return rc;
+    if (int rc = upload_vec(R->d_tasks, R->tasks, s)) return rc;
+    if (int rc = upload_vec(R->d_neg_inf_idx, R->neg_inf_idx, s)) return rc;
+    HIP_TRY(R->d_out.ensure(std::max<size_t>(static_cast<size_t>(pairs) * sizeof(double), 16)));
+    HIP_TRY(R->d_rerun_lists.ensure(std::max<size_t>(R->tasks.size() * sizeof(int32_t), 16)));
+    HIP_TRY(R->d_counters.ensure(256));
+    // the host vectors above are pageable and die with this scope: finish the copies first
+    HIP_TRY(hipStreamSynchronize(s));
+    return GATK_PAIRHMM_OK;
+}
+
+// counters layout: [0] error word, [1 + b] rerun count of bucket b
+constexpr int kMaxBuckets = kMaxRowsPerLane;
+
+int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const bool timing = h->timing && g_num_threads.load() == 1;
+    if (timing)
+        for (auto& e : R->ev)
+            if (!e) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipMemsetAsync(R->d_counters.p, 0, 256, s));
+    DeviceBatch B{};
+    B.read_bases = R->d_read_bases.as<uint8_t>();
+    B.read_quals = R->d_read_quals.as<uint8_t>();
+    B.ins_gop = R->d_ins.as<uint8_t>();
+    B.del_gop = R->d_del.as<uint8_t>();
+    B.gcp = R->d_gcp.as<uint8_t>();
+    B.read_off = R->d_read_off.as<int32_t>();
+    B.read_out_base = R->d_read_out_base.as<int32_t>();
+    B.hap_pool = R->d_hap_pool.as<uint8_t>();
+    B.hap_off = R->d_hap_off.as<int32_t>();
+    B.hap_len = R->d_hap_len.as<int32_t>();
+    B.hap_local = R->d_hap_local.as<int32_t>();
+    B.lanes = R->d_lanes.as<LaneDesc>();
+    B.group_fill = R->d_group_fill.as<int32_t>();
+    B.err_prob = h->d_err;
+    B.match_to_match = h->d_mm;
+    B.out = R->d_out.as<double>();
+    B.error_word = R->d_counters.as<int32_t>();
+    B.fp32_threshold = h->fp32_threshold;
+    B.total_read_bytes = R->total_read_bytes;
+    HIP_TRY(launch_validate(B, s));
+    if (!R->neg_inf_idx.empty())
+        HIP_TRY(launch_fill_neg_inf(B.out, R->d_neg_inf_idx.as<int32_t>(), static_cast<int>(R->neg_inf_idx.size()), s));
+    if (timing) HIP_TRY(hipEventRecord(R->ev[0], s));
+    for (size_t bi = 0; bi < R->buckets.size(); ++bi) {
+        const Bucket& bk = R->buckets[bi];
+        DeviceBatch L = B;
+        L.tasks = R->d_tasks.as<Task>() + bk.task_begin;
+        L.num_tasks = bk.num_tasks;
+        L.rerun_count = R->d_counters.as<int32_t>() + 1 + bi;
+        L.rerun_list = R->d_rerun_lists.as<int32_t>() + bk.task_begin;
+        L.lds_per_wave = bk.lds_per_wave;
+        const int blocks = (bk.num_tasks + kWavesPerBlock - 1) / kWavesPerBlock;
+        HIP_TRY(launch_forward(L, bk.rows_per_lane, bk.hap_has_n, h->force_fp64, false, blocks, s));
+    }
+    if (timing) HIP_TRY(hipEventRecord(R->ev[1], s));
+    if (!h->force_fp64) {
+        for (size_t bi = 0; bi < R->buckets.size(); ++bi) {
+            const Bucket& bk = R->buckets[bi];
+            DeviceBatch L = B;
+            L.tasks = R->d_tasks.as<Task>() + bk.task_begin;
+            L.num_tasks = bk.num_tasks;
+            L.rerun_count = R->d_counters.as<int32_t>() + 1 + bi;
+            L.rerun_list = R->d_rerun_lists.as<int32_t>() + bk.task_begin;
+            L.lds_per_wave = bk.lds_per_wave;
+            const int blocks = std::min((bk.num_tasks + kWavesPerBlock - 1) / kWavesPerBlock, 1024);
+            HIP_TRY(launch_forward(L, bk.rows_per_lane, bk.hap_has_n, true, true, blocks, s));
+        }
+    }
+    if (timing) HIP_TRY(hipEventRecord(R->ev[2], s));
+    R->computed = true;
+    return GATK_PAIRHMM_OK;
+}
+
+// Wait for the stream, turn the device error word into the reference's exception code, fill stats.
+int finish_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    int32_t counters[1 + kMaxBuckets] = {0};
+    HIP_TRY(hipMemcpy(counters, R->d_counters.p, sizeof counters, hipMemcpyDeviceToHost));
+    gatk_pairhmm_stats st{};
+    st.pairs = R->total_pairs;
+    st.cells = R->cells;
+    st.wave_tasks = static_cast<int64_t>(R->tasks.size());
+    for (size_t bi = 0; bi < R->buckets.size(); ++bi) {
+        const int n = std::min(counters[1 + bi], R->buckets[bi].num_tasks);
+        st.rerun_tasks += n;
+        if (n > 0) {
+            std::vector<int32_t> list(n);
+            HIP_TRY(hipMemcpy(list.data(), R->d_rerun_lists.as<int32_t>() + R->buckets[bi].task_begin, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+            for (int t : list) st.rerun_pairs += R->group_segs[R->tasks[R->buckets[bi].task_begin + t].group];
+        }
+    }
+    if (h->timing && g_num_threads.load() == 1 && R->ev[0]) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, R->ev[0], R->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&b, R->ev[1], R->ev[2]));
+        st.fp32_kernel_ms = a; st.fp64_kernel_ms = b;
+    }
+    h->stats = st;
+    if (counters[0] & 1) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "insert quality, deletion quality or gcp cannot be less than 0 (byte >= 128)");
+    if (counters[0] & 2) return fail(GATK_PAIRHMM_INDEX_OUT_OF_BOUNDS, "base quality 255 is outside the 255-entry error-probability cache");
+    return GATK_PAIRHMM_OK;
+}
+
+int download_into(gatk_pairhmm* h, gatk_pairhmm_resident* R, double* const* outs) {
+    if (int rc = finish_compute(h, R)) return rc;
+    if (R->total_pairs == 0) return GATK_PAIRHMM_OK;
+    // one region, or regions that are contiguous in the caller's memory, need no staging copy
+    std::vector<double> stage;
+    for (int k = 0; k < R->num_regions; ++k) {
+        const int64_t n = R->region_out_off[k + 1] - R->region_out_off[k];
+        if (n == 0) continue;
+        if (!outs || !outs[k]) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "likelihoods cannot be null");
+        HIP_TRY(hipMemcpy(outs[k], R->d_out.as<double>() + R->region_out_off[k], n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return GATK_PAIRHMM_OK;
+}
+
+int check_handle(gatk_pairhmm* h) {
+    if (!h) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "PairHMM handle cannot be null");
+    return GATK_PAIRHMM_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char* gatk_pairhmm_last_error(void) { return g_last_error.c_str(); }
+const char* gatk_pairhmm_version(void) { return "gatk_pairhmm_hip 0.1 (gfx950)"; }
+
+int gatk_pairhmm_device_count(int32_t* count) {
+    if (!count) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "count cannot be null");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_set_number_of_threads(int32_t num_threads) {
+    g_num_threads.store(num_threads);
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_create(int device, gatk_pairhmm** out) {
+    if (!out) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "out cannot be null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(GATK_PAIRHMM_DEVICE_ERROR, "no HIP device is visible: the PairHMM engine has no CPU fallback");
+    if (device < 0 || device >= n) return fail(GATK_PAIRHMM_DEVICE_ERROR, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    gatk_pairhmm* h = new gatk_pairhmm();
+    h->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    const Tables& t = tables();
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_err), sizeof t.err_prob);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_mm), t.match_to_match.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(h->d_err, t.err_prob, sizeof t.err_prob, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(h->d_mm, t.match_to_match.data(), t.match_to_match.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        const int rc = fail(GATK_PAIRHMM_DEVICE_ERROR, std::string("device set-up failed: ") + hipGetErrorString(e));
+        gatk_pairhmm_close(h);
+        return rc;
+    }
+    *out = h;
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_initialize(gatk_pairhmm* h, int32_t read_max_length, int32_t haplotype_max_length) {
+    if (int rc = check_handle(h)) return rc;
+    if (read_max_length <= 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "READ_MAX_LENGTH must be > 0 but got " + std::to_string(read_max_length));
+    if (haplotype_max_length <= 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "HAPLOTYPE_MAX_LENGTH must be > 0 but got " + std::to_string(haplotype_max_length));
+    h->max_read = read_max_length;
+    h->max_hap = haplotype_max_length;
+    h->initialized = true;
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
+                                 double* const* likelihoods) {
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = plan_and_upload(h, &h->scratch, num_regions, regions)) return rc;
+    if (h->scratch.total_pairs == 0) { h->stats = gatk_pairhmm_stats{}; return GATK_PAIRHMM_OK; }
+    if (int rc = enqueue_compute(h, &h->scratch)) return rc;
+    return download_into(h, &h->scratch, likelihoods);
+}
+
+int gatk_pairhmm_compute_likelihoods(gatk_pairhmm* h, const gatk_pairhmm_batch* batch, double* likelihoods) {
+    if (int rc = check_handle(h)) return rc;
+    if (!batch) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "batch cannot be null");
+    if (batch->num_reads == 0) return GATK_PAIRHMM_OK;  // PairHMM.java:193
+    const int64_t n = static_cast<int64_t>(batch->num_reads) * std::max(batch->num_haps, 0);
+    if (n > 0 && !likelihoods) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "likelihoods cannot be null");
+    double* outs[1] = {likelihoods};
+    if (int rc = gatk_pairhmm_compute_regions(h, 1, batch, outs)) return rc;
+    h->likelihood_array.assign(likelihoods, likelihoods + n);  // mLikelihoodArray, PairHMM.java:206,225
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_compute_likelihoods_ptrs(gatk_pairhmm* h, int32_t num_reads, int32_t num_haps,
+                                          const uint8_t* const* read_bases, const uint8_t* const* read_quals,
+                                          const uint8_t* const* ins_gop, const uint8_t* const* del_gop,
+                                          const uint8_t* const* gcp, const int32_t* read_lengths,
+                                          const uint8_t* const* hap_bases, const int32_t* hap_lengths,
+                                          double* likelihoods) {
+    if (int rc = check_handle(h)) return rc;
+    if (num_reads == 0) return GATK_PAIRHMM_OK;
+    if (num_reads < 0 || num_haps < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "negative read or haplotype count");
+    if (!read_bases || !read_quals || !ins_gop || !del_gop || !gcp || !read_lengths)
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "readBases cannot be null");
+    if (num_haps > 0 && (!hap_bases || !hap_lengths)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "haplotypeBases cannot be null");
+    std::vector<uint8_t> rb, rq, ri, rd, rg, hb;
+    std::vector<int32_t> ro{0}, ho{0};
+    for (int r = 0; r < num_reads; ++r) {
+        const int len = read_lengths[r];
+        if (len < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "negative read length");
+        if (len > 0 && (!read_bases[r] || !read_quals[r] || !ins_gop[r] || !del_gop[r] || !gcp[r]))
+            return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "readBases cannot be null");
+        rb.insert(rb.end(), read_bases[r], read_bases[r] + len);
+        rq.insert(rq.end(), read_quals[r], read_quals[r] + len);
+        ri.insert(ri.end(), ins_gop[r], ins_gop[r] + len);
+        rd.insert(rd.end(), del_gop[r], del_gop[r] + len);
+        rg.insert(rg.end(), gcp[r], gcp[r] + len);
+        ro.push_back(static_cast<int32_t>(rb.size()));
+    }
+    for (int a = 0; a < num_haps; ++a) {
+        const int len = hap_lengths[a];
+        if (len < 0 || (len > 0 && !hap_bases[a])) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "haplotypeBases cannot be null");
+        hb.insert(hb.end(), hap_bases[a], hap_bases[a] + len);
+        ho.push_back(static_cast<int32_t>(hb.size()));
+    }
+    // keep the data pointers non-null for empty payloads
+    rb.push_back(0); rq.push_back(0); ri.push_back(0); rd.push_back(0); rg.push_back(0); hb.push_back(0);
+    gatk_pairhmm_batch b{num_reads, num_haps, rb.data(), rq.data(), ri.data(), rd.data(), rg.data(), ro.data(), hb.data(), ho.data()};
+    return gatk_pairhmm_compute_likelihoods(h, &b, likelihoods);
+}
+
+int gatk_pairhmm_compute_pair(gatk_pairhmm* h, const uint8_t* hap_bases, int32_t hap_length,
+                              const uint8_t* read_bases, const uint8_t* read_quals, const uint8_t* ins_gop,
+                              const uint8_t* del_gop, const uint8_t* gcp, int32_t read_length, double* likelihood) {
+    if (int rc = check_handle(h)) return rc;
+    // PairHMM.java:271-279
+    if (!h->initialized) return fail(GATK_PAIRHMM_ILLEGAL_STATE, "Must call initialize before calling computeReadLikelihoodGivenHaplotypeLog10");
+    if (!hap_bases) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "haplotypeBases cannot be null");
+    if (hap_length > h->max_hap) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "Haplotype bases is too long, got " + std::to_string(hap_length) + " but max is " + std::to_string(h->max_hap));
+    if (!read_bases) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "readBases cannot be null");
+    if (read_length > h->max_read) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "readBases is too long, got " + std::to_string(read_length) + " but max is " + std::to_string(h->max_read));
+    if (!read_quals || !ins_gop || !del_gop || !gcp) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "Read bases and read quals aren't the same size");
+    if (!likelihood) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "likelihood cannot be null");
+    if (read_length == 0 && hap_length > 0) { *likelihood = -std::numeric_limits<double>::infinity(); return GATK_PAIRHMM_OK; }
+    const int32_t ro[2] = {0, read_length}, ho[2] = {0, hap_length};
+    gatk_pairhmm_batch b{1, 1, read_bases, read_quals, ins_gop, del_gop, gcp, ro, hap_bases, ho};
+    double* outs[1] = {likelihood};
+    return gatk_pairhmm_compute_regions(h, 1, &b, outs);
+}
+
+int gatk_pairhmm_batch_add(gatk_pairhmm* h, int32_t num_haps, const uint8_t* const* hap_bases,
+                           const int32_t* hap_lengths, const uint8_t* read_bases, const uint8_t* read_quals,
+                           const uint8_t* ins_gop, const uint8_t* del_gop, const uint8_t* gcp, int32_t read_length) {
+    if (int rc = check_handle(h)) return rc;
+    if (num_haps < 0 || read_length < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "negative count");
+    if (!read_bases || !read_quals || !ins_gop || !del_gop || !gcp) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "readBases cannot be null");
+    if (num_haps > 0 && (!hap_bases || !hap_lengths)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "haplotypeBases cannot be null");
+    gatk_pairhmm::Queued q;
+    q.bases.assign(read_bases, read_bases + read_length);
+    q.quals.assign(read_quals, read_quals + read_length);
+    q.ins.assign(ins_gop, ins_gop + read_length);
+    q.del.assign(del_gop, del_gop + read_length);
+    q.gcp.assign(gcp, gcp + read_length);
+    q.hap_off.push_back(0);
+    for (int a = 0; a < num_haps; ++a) {
+        if (hap_lengths[a] < 0 || !hap_bases[a]) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "haplotypeBases cannot be null");
+        q.haps.insert(q.haps.end(), hap_bases[a], hap_bases[a] + hap_lengths[a]);
+        q.hap_off.push_back(static_cast<int32_t>(q.haps.size()));
+    }
+    for (auto* v : {&q.bases, &q.quals, &q.ins, &q.del, &q.gcp, &q.haps}) v->push_back(0);
+    h->queue.push_back(std::move(q));
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_batch_get_result(gatk_pairhmm* h, const double** results, int64_t* count) {
+    if (int rc = check_handle(h)) return rc;
+    if (!results || !count) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "results cannot be null");
+    const size_t n = h->queue.size();
+    std::vector<gatk_pairhmm_batch> regions(n);
+    std::vector<std::vector<int32_t>> ro(n);
+    std::vector<double*> outs(n);
+    int64_t total = 0;
+    for (size_t k = 0; k < n; ++k) total += static_cast<int64_t>(h->queue[k].hap_off.size()) - 1;
+    h->queue_results.assign(static_cast<size_t>(total), 0.0);
+    int64_t off = 0;
+    for (size_t k = 0; k < n; ++k) {
+        auto& q = h->queue[k];
+        ro[k] = {0, static_cast<int32_t>(q.bases.size()) - 1};
+        regions[k] = gatk_pairhmm_batch{1, static_cast<int32_t>(q.hap_off.size()) - 1, q.bases.data(), q.quals.data(), q.ins.data(),
+                                        q.del.data(), q.gcp.data(), ro[k].data(), q.haps.data(), q.hap_off.data()};
+        outs[k] = h->queue_results.data() + off;
+        off += regions[k].num_haps;
+    }
+    const int rc = n ? gatk_pairhmm_compute_regions(h, static_cast<int32_t>(n), regions.data(), outs.data()) : GATK_PAIRHMM_OK;
+    h->queue.clear();
+    if (rc) return rc;
+    *results = h->queue_results.data();
+    *count = total;
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_get_likelihood_array(gatk_pairhmm* h, const double** array, int64_t* count) {
+    if (int rc = check_handle(h)) return rc;
+    if (!array || !count) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "array cannot be null");
+    *array = h->likelihood_array.data();
+    *count = static_cast<int64_t>(h->likelihood_array.size());
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_finalize_region(gatk_pairhmm* h) {
+    if (int rc = check_handle(h)) return rc;
+    h->queue.clear();
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_close(gatk_pairhmm* h) {
+    if (!h) return GATK_PAIRHMM_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->scratch.release();
+    if (h->d_err) (void)hipFree(h->d_err);
+    if (h->d_mm) (void)hipFree(h->d_mm);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_get_stats(gatk_pairhmm* h, gatk_pairhmm_stats* out) {
+    if (int rc = check_handle(h)) return rc;
+    if (!out) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "out cannot be null");
+    *out = h->stats;
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
+    if (int rc = check_handle(h)) return rc;
+    if (!name) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "name cannot be null");
+    const std::string n(name);
+    if (n == "fp32_threshold") h->fp32_threshold = static_cast<float>(value);
+    else if (n == "force_rows_per_lane") h->force_rows_per_lane = static_cast<int>(value);
+    else if (n == "force_fp64") h->force_fp64 = value != 0;
+    else if (n == "timing") h->timing = value != 0;
+    else return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "unknown option " + n);
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_upload(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
+                        gatk_pairhmm_resident** out) {
+    if (int rc = check_handle(h)) return rc;
+    if (!out) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "out cannot be null");
+    *out = nullptr;
+    auto* R = new gatk_pairhmm_resident();
+    if (int rc = plan_and_upload(h, R, num_regions, regions)) {
+        R->release();
+        delete R;
+        return rc;
+    }
+    *out = R;
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_compute_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, int32_t sync) {
+    if (int rc = check_handle(h)) return rc;
+    if (!r) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "resident batch cannot be null");
+    if (r->total_pairs > 0)
+        if (int rc = enqueue_compute(h, r)) return rc;
+    if (sync) return finish_compute(h, r);
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_download(gatk_pairhmm* h, gatk_pairhmm_resident* r, double* const* likelihoods) {
+    if (int rc = check_handle(h)) return rc;
+    if (!r) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "resident batch cannot be null");
+    if (r->total_pairs > 0 && !r->computed) return fail(GATK_PAIRHMM_ILLEGAL_STATE, "download before compute_resident");
+    return download_into(h, r, likelihoods);
+}
+
+int gatk_pairhmm_resident_free(gatk_pairhmm* h, gatk_pairhmm_resident* r) {
+    if (int rc = check_handle(h)) return rc;
+    if (!r) return GATK_PAIRHMM_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    r->release();
+    delete r;
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_get_stream(gatk_pairhmm* h, void** stream) {
+    if (int rc = check_handle(h)) return rc;
+    if (!stream) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "stream cannot be null");
+    *stream = h->stream;
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_resident_device_output(gatk_pairhmm_resident* r, void** device_ptr, int64_t* count) {
+    if (!r || !device_ptr || !count) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "argument cannot be null");
+    *device_ptr = r->d_out.p;
+    *count = r->total_pairs;
+    return GATK_PAIRHMM_OK;
+}
+
+}  // extern "C"

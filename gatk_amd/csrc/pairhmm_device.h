@@ -1,0 +1,58 @@
+// Structures shared by the host planner and the HIP kernels.
+#pragma once
+#include <cstdint>
+
+namespace pairhmm_hip {
+
+// Number of read rows a lane can own (template instantiations of the forward kernel).
+constexpr int kMaxRowsPerLane = 8;
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kHapFrontPad = 64;  // bytes in front of the LDS haplotype image: lanes ahead of column 1 read here
+
+// One lane of a wave-group.  A wave-group packs one or more reads into the 64 lanes of a
+// wavefront: a read of length R takes ceil(R/K) consecutive lanes ("segment"), each lane owning K
+// consecutive read rows; the unused rows are put in FRONT of row 1 so that the read's last row is
+// always row K-1 of the segment's last lane.
+struct LaneDesc {
+    int32_t read_idx;   // read owning this lane, or -1 for an unused lane
+    int32_t first_row;  // 1-based read row of this lane's row 0; <= 0 means leading pad rows
+    int32_t seg_lane;   // lane index inside the segment (0 = segment start)
+    int32_t seg_last;   // 1 if this lane holds the read's last row
+};
+
+// One wavefront work item: a wave-group scored against one haplotype.
+struct Task {
+    int32_t group;
+    int32_t hap;
+};
+
+// Kernel arguments.  All pointers are device pointers.
+struct DeviceBatch {
+    const uint8_t* read_bases;
+    const uint8_t* read_quals;
+    const uint8_t* ins_gop;
+    const uint8_t* del_gop;
+    const uint8_t* gcp;
+    const int32_t* read_off;       // [num_reads + 1]
+    const int32_t* read_out_base;  // [num_reads] index in out[] of (read, haplotype 0 of its region)
+    const uint8_t* hap_pool;       // haplotype bytes, each haplotype starting on a 16-byte boundary
+    const int32_t* hap_off;        // [num_haps] byte offset into hap_pool
+    const int32_t* hap_len;        // [num_haps]
+    const int32_t* hap_local;      // [num_haps] index of the haplotype inside its region
+    const LaneDesc* lanes;         // [num_groups * 64]
+    const int32_t* group_fill;     // [num_groups] lanes of the longest segment minus one
+    const Task* tasks;             // this launch's tasks
+    int32_t num_tasks;
+    const double* err_prob;        // [256]
+    const double* match_to_match;  // [128 * 128]
+    double* out;
+    int32_t* rerun_count;          // this launch's rerun list length
+    int32_t* rerun_list;           // this launch's rerun list: indices into tasks
+    int32_t* error_word;
+    float fp32_threshold;
+    int32_t lds_per_wave;          // bytes of LDS each wave owns
+    int64_t total_read_bytes;
+};
+
+}  // namespace pairhmm_hip

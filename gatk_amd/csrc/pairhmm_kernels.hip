@@ -1,0 +1,343 @@
+// PairHMM forward kernels for gfx950 (MI355X, wave64).
+//
+// What is computed (linear-space form of the reference recurrence,
+// pairhmm/Log10PairHMM.java:108-113,211-219 with pairhmm/PairHMMModel.java:135-144 transitions):
+//   M[i][j] = prior[i][j] * ( M[i-1][j-1]*t[i][0] + (I[i-1][j-1] + D[i-1][j-1])*t[i][1] )
+//   I[i][j] =                 M[i-1][j]  *t[i][2] +  I[i-1][j]  *t[i][3]
+//   D[i][j] =                 M[i][j-1]  *t[i][4] +  D[i][j-1]  *t[i][5]
+//   result  = log10( sum_j M[R][j] + I[R][j] ) - log10(scale),  D[0][j] = scale / H
+//
+// How it is laid out on a wavefront:
+//   * a wave owns a wave-group (one or more reads packed into lane segments, K read rows per
+//     lane) and one haplotype; at step s the lane at segment position t works on haplotype
+//     column s - t, so the wave sweeps anti-diagonals and a segment of L lanes needs H + L - 1
+//     steps;
+//   * the only values that cross lanes are, for the lane's LAST row, what the next read row
+//     needs from it: Sn = M*t0' + (I + D)*t1' (the bracket of the next row's M one column later)
+//     and In = M*t2' + I*t3' (the next row's I in this column), primed = next row's transitions.
+//     Both move one lane up with a single v_mov_b32_dpp wave_shr:1 each per step;
+//   * the rows inside a lane hand the same two values down through registers;
+//   * haplotype bases sit in an LDS image private to the wave; per-row constants (prior for
+//     match / mismatch, six transitions) are expanded once per task from the read's quality bytes
+//     through look-up tables and stay in registers;
+//   * lanes outside 1 <= column <= H are masked off, so every pair starts from exact boundary
+//     values and no pair ever reads another pair's state.
+//
+// fp32 runs with scale 2^120; a task in which some pair's final sum is below the threshold
+// is queued and recomputed by the same code in fp64 with scale 2^1020.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "pairhmm_device.h"
+
+namespace pairhmm_hip {
+
+namespace {
+
+__device__ __forceinline__ float shr1(float v) {
+    // lane l receives lane l-1's value; lane 0 receives 0
+    const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    return __builtin_bit_cast(float, r);
+}
+
+__device__ __forceinline__ double shr1(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(b), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(b >> 32), 0x138, 0xf, 0xf, true);
+    const long long r = (static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo);
+    return __builtin_bit_cast(double, r);
+}
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+template <typename T> struct Scale;
+template <> struct Scale<float> { static constexpr int kExp2 = 120; };
+template <> struct Scale<double> { static constexpr int kExp2 = 1020; };
+
+constexpr unsigned kNoBase = 0x100;  // compares unequal to every haplotype byte
+
+// Keeps a per-row constant in a register of its own type: without it the compiler carries the
+// double it was converted from through the loop and converts after every select.
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(double& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(unsigned& x) { asm volatile("" : "+v"(x)); }
+
+// Registers of one lane: K read rows.
+//   E  = D / matchToDeletion of the row (so the deletion recurrence is one fma: E' = M + E*t5)
+//   Sd = hand-off Sn of the row above, one column back (the bracket of this row's M)
+template <typename T, int K>
+struct Rows {
+    unsigned XB[K];
+    T P[K], Q[K], T5[K], T0N[K], T1N[K], T2N[K], T3N[K], T41N[K];
+    T Ml[K], El[K], Sd[K];
+    T Sout, Iout, acc;
+};
+
+// One haplotype column for all K rows of the lane.  Sin / Iin: hand-off of the row above the
+// lane's first row in this column.
+template <typename T, int K, bool HAPN>
+__device__ __forceinline__ void column(Rows<T, K>& w, const unsigned yb, const T Sin, const T Iin) {
+    T Iup = Iin;    // I of the current row in this column
+    T Snext = Sin;  // Sn of the row above in this column: next column's diagonal term
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        bool match = (yb == w.XB[r]);
+        if (HAPN) match = match || (yb == 'N');
+        const T prior = match ? w.P[r] : w.Q[r];
+        const T M = prior * w.Sd[r];
+        const T E = fma_(w.El[r], w.T5[r], w.Ml[r]);
+        const T In = fma_(M, w.T2N[r], Iup * w.T3N[r]);
+        const T Sn = fma_(E, w.T41N[r], fma_(Iup, w.T1N[r], M * w.T0N[r]));
+        if (r == K - 1) w.acc += M + Iup;
+        w.Ml[r] = M;
+        w.El[r] = E;
+        w.Sd[r] = Snext;
+        Snext = Sn;
+        Iup = In;
+    }
+    w.Sout = Snext;
+    w.Iout = Iup;
+}
+
+template <typename T, int K, bool HAPN>
+__device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_idx, unsigned char* slice,
+                                         const int lane, const bool queue_underflow) {
+    const Task tk = B.tasks[task_idx];
+    const int H = B.hap_len[tk.hap];
+    const int fill = B.group_fill[tk.group];
+    const LaneDesc ld = B.lanes[tk.group * kWave + lane];
+
+    // ---- haplotype bases -> this wave's LDS image --------------------------------------------
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(B.hap_pool + B.hap_off[tk.hap]);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(slice + kHapFrontPad);
+        const int words = (H + 3) >> 2;
+        for (int d = lane; d < words; d += kWave) dst[d] = src[d];
+    }
+
+    // ---- per-row constants ---------------------------------------------------------------------
+    const T initD = static_cast<T>(::ldexp(1.0, Scale<T>::kExp2) / static_cast<double>(H));
+    int ro = 0, R = 0;
+    if (ld.read_idx >= 0) {
+        ro = B.read_off[ld.read_idx];
+        R = B.read_off[ld.read_idx + 1] - ro;
+    }
+    Rows<T, K> w;
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        const int i = ld.first_row + r;  // 1-based read row
+        double p = 0, q = 0, t4 = 0, t5 = 0, t0n = 0, t1n = 0, t2n = 0, t3n = 0;
+        bool pad = false;
+        unsigned xb = kNoBase;
+        if (ld.read_idx >= 0) {
+            if (i >= 1) {
+                const unsigned x = B.read_bases[ro + i - 1];
+                const double e = B.err_prob[B.read_quals[ro + i - 1]];
+                xb = x;
+                p = 1.0 - e;                             // QualityUtils.qualToProb
+                q = (x == 'N') ? p : e / 3.0;            // a read 'N' matches every base
+                t4 = B.err_prob[B.del_gop[ro + i - 1]];  // matchToDeletion
+                t5 = B.err_prob[B.gcp[ro + i - 1]];      // deletionToDeletion
+            } else {
+                // leading pad row: behaves as matrix row 0 (M = I = 0, D = scale / H in every column)
+                pad = true;
+                t4 = 1.0;
+                t5 = 1.0;
+                if (i < 0) t1n = 1.0;
+            }
+            if (i >= 0 && i < R) {  // transitions of read row i+1, taken from quals[i]
+                const unsigned ins = B.ins_gop[ro + i] & 127u, del = B.del_gop[ro + i] & 127u;
+                const double eg = B.err_prob[B.gcp[ro + i]];
+                t1n = 1.0 - eg;  // indelToMatch
+                if (i >= 1) {
+                    t0n = B.match_to_match[ins * 128u + del];
+                    t2n = B.err_prob[ins];  // matchToInsertion
+                    t3n = eg;               // insertionToInsertion
+                }
+            }
+        }
+        w.XB[r] = xb;
+        w.P[r] = static_cast<T>(p); w.Q[r] = static_cast<T>(q);
+        w.T5[r] = static_cast<T>(t5);
+        w.T0N[r] = static_cast<T>(t0n); w.T1N[r] = static_cast<T>(t1n);
+        w.T2N[r] = static_cast<T>(t2n); w.T3N[r] = static_cast<T>(t3n);
+        w.T41N[r] = static_cast<T>(t4 * t1n);
+        w.Ml[r] = static_cast<T>(0);
+        w.El[r] = pad ? initD : static_cast<T>(0);  // column 0
+        pin(w.XB[r]); pin(w.P[r]); pin(w.Q[r]); pin(w.T5[r]); pin(w.T0N[r]); pin(w.T1N[r]);
+        pin(w.T2N[r]); pin(w.T3N[r]); pin(w.T41N[r]);
+    }
+    // column-0 hand-offs: Sn of the row above, where M = I = 0
+#pragma unroll
+    for (int r = 1; r < K; ++r) w.Sd[r] = w.El[r - 1] * w.T41N[r - 1];
+    w.Sout = w.El[K - 1] * w.T41N[K - 1];
+    w.Iout = static_cast<T>(0);
+    w.acc = static_cast<T>(0);
+    const bool seg_start = ld.seg_lane == 0;
+    // what matrix row 0 hands to read row 1: Sn = (scale / H) * indelToMatch(row 1), In = 0
+    T s_inject = static_cast<T>(0);
+    if (ld.read_idx >= 0 && seg_start && R > 0) s_inject = initD * static_cast<T>(1.0 - B.err_prob[B.gcp[ro]]);
+    {
+        const T up = shr1(w.Sout);
+        w.Sd[0] = seg_start ? s_inject : up;
+    }
+
+    // ---- anti-diagonal sweep -------------------------------------------------------------------
+    // step s: the lane at segment position t works on haplotype column s - t (0-based).
+    //   [0, fill)            pipeline fill: lanes with s < t wait              -> masked
+    //   [fill, H)            every lane of every segment is inside 0..H-1      -> no mask
+    //   [max(H, fill), H+fill) pipeline drain: lanes with s - t >= H are done  -> masked
+    const unsigned char* hp = slice + (kHapFrontPad - ld.seg_lane);
+    const T zero = static_cast<T>(0);
+    __builtin_amdgcn_wave_barrier();
+    auto masked_step = [&](const int s) {
+        T Sin = shr1(w.Sout);
+        T Iin = shr1(w.Iout);
+        Sin = seg_start ? s_inject : Sin;
+        Iin = seg_start ? zero : Iin;
+        const unsigned yb = hp[s];
+        if (static_cast<unsigned>(s - ld.seg_lane) < static_cast<unsigned>(H)) column<T, K, HAPN>(w, yb, Sin, Iin);
+    };
+    const int steady_begin = fill < H ? fill : H;
+    for (int s = 0; s < steady_begin; ++s) masked_step(s);
+    int s = steady_begin;
+    if (s + 4 <= H) {
+        unsigned n0 = hp[s], n1 = hp[s + 1], n2 = hp[s + 2], n3 = hp[s + 3];
+        for (; s + 4 <= H; s += 4) {
+            const unsigned y0 = n0, y1 = n1, y2 = n2, y3 = n3;
+            // next iteration's bases; reads past H land in the image's tail padding
+            n0 = hp[s + 4]; n1 = hp[s + 5]; n2 = hp[s + 6]; n3 = hp[s + 7];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                T Sin = shr1(w.Sout);
+                T Iin = shr1(w.Iout);
+                Sin = seg_start ? s_inject : Sin;
+                Iin = seg_start ? zero : Iin;
+                column<T, K, HAPN>(w, u == 0 ? y0 : u == 1 ? y1 : u == 2 ? y2 : y3, Sin, Iin);
+            }
+        }
+    }
+    for (; s < H + fill; ++s) masked_step(s);
+
+    // ---- termination ---------------------------------------------------------------------------
+    bool under = false;
+    if (ld.seg_last != 0 && ld.read_idx >= 0) {
+        const double res = ::log10(static_cast<double>(w.acc)) - Scale<T>::kExp2 * 0.30102999566398119521;
+        B.out[B.read_out_base[ld.read_idx] + B.hap_local[tk.hap]] = res;
+        if (std::is_same<T, float>::value) under = !(static_cast<float>(w.acc) >= B.fp32_threshold);
+    }
+    if (queue_underflow) {
+        if (__any(under ? 1 : 0)) {
+            if (lane == 0) {
+                const int pos = atomicAdd(B.rerun_count, 1);
+                B.rerun_list[pos] = task_idx;
+            }
+        }
+    }
+}
+
+// One task per wave, tasks taken in launch order.
+template <typename T, int K, bool HAPN>
+__global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_direct(const DeviceBatch B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int task = blockIdx.x * kWavesPerBlock + wave;
+    if (task >= B.num_tasks) return;
+    run_task<T, K, HAPN>(B, task, lds + wave * B.lds_per_wave, lane, std::is_same<T, float>::value);
+}
+
+// Tasks taken from the device-side rerun list; every wave strides over the list, so the grid
+// size does not depend on the (device-only) list length and each wave leaves when the list ends.
+template <typename T, int K, bool HAPN>
+__global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_list(const DeviceBatch B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & (kWave - 1);
+    int n = *B.rerun_count;
+    if (n > B.num_tasks) n = B.num_tasks;
+    const int stride = gridDim.x * kWavesPerBlock;
+    for (int it = blockIdx.x * kWavesPerBlock + wave; it < n; it += stride) {
+        const int task = __builtin_amdgcn_readfirstlane(B.rerun_list[it]);
+        run_task<T, K, HAPN>(B, task, lds + wave * B.lds_per_wave, lane, false);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Input validation: the checks the reference makes while expanding a read's qualities
+// (PairHMMModel.java:136-138: negative ins/del/GCP byte -> IllegalArgumentException;
+// QualityUtils.java:173: base quality 255 indexes past the 255-entry cache).
+__global__ void __launch_bounds__(256) validate_quals(const DeviceBatch B) {
+    const int64_t n = B.total_read_bytes;
+    int bad = 0;
+    for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n;
+         k += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        if ((B.ins_gop[k] | B.del_gop[k] | B.gcp[k]) & 0x80) bad |= 1;
+        if (B.read_quals[k] == 255) bad |= 2;
+    }
+    if (bad) atomicOr(B.error_word, bad);
+}
+
+// Zero-length reads: the last matrix row is row 0, whose M and I are all zero -> log10(0).
+__global__ void __launch_bounds__(256) fill_neg_inf(double* out, const int32_t* idx, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[idx[k]] = -__builtin_inf();
+}
+
+template <typename T, int K>
+hipError_t launch_k(const DeviceBatch& B, bool hapn, bool list_mode, int blocks, hipStream_t stream) {
+    const size_t lds = static_cast<size_t>(B.lds_per_wave) * kWavesPerBlock;
+    const dim3 grid(blocks), block(kWave * kWavesPerBlock);
+    if (list_mode) {
+        if (hapn) hipLaunchKernelGGL((fwd_list<T, K, true>), grid, block, lds, stream, B);
+        else hipLaunchKernelGGL((fwd_list<T, K, false>), grid, block, lds, stream, B);
+    } else {
+        if (hapn) hipLaunchKernelGGL((fwd_direct<T, K, true>), grid, block, lds, stream, B);
+        else hipLaunchKernelGGL((fwd_direct<T, K, false>), grid, block, lds, stream, B);
+    }
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_t(const DeviceBatch& B, int K, bool hapn, bool list_mode, int blocks, hipStream_t stream) {
+    switch (K) {
+        case 1: return launch_k<T, 1>(B, hapn, list_mode, blocks, stream);
+        case 2: return launch_k<T, 2>(B, hapn, list_mode, blocks, stream);
+        case 3: return launch_k<T, 3>(B, hapn, list_mode, blocks, stream);
+        case 4: return launch_k<T, 4>(B, hapn, list_mode, blocks, stream);
+        case 5: return launch_k<T, 5>(B, hapn, list_mode, blocks, stream);
+        case 6: return launch_k<T, 6>(B, hapn, list_mode, blocks, stream);
+        case 7: return launch_k<T, 7>(B, hapn, list_mode, blocks, stream);
+        case 8: return launch_k<T, 8>(B, hapn, list_mode, blocks, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+// Enqueue the forward kernel for one bucket of tasks.  list_mode: take task indices from the
+// bucket's rerun list (fp64 pass) instead of 0..num_tasks-1.
+hipError_t launch_forward(const DeviceBatch& B, int rows_per_lane, bool hap_has_n, bool fp64, bool list_mode,
+                          int blocks, hipStream_t stream) {
+    if (B.num_tasks <= 0 || blocks <= 0) return hipSuccess;
+    return fp64 ? launch_t<double>(B, rows_per_lane, hap_has_n, list_mode, blocks, stream)
+                : launch_t<float>(B, rows_per_lane, hap_has_n, list_mode, blocks, stream);
+}
+
+hipError_t launch_fill_neg_inf(double* out, const int32_t* idx, int n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_neg_inf, dim3((n + 255) / 256), dim3(256), 0, stream, out, idx, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_validate(const DeviceBatch& B, hipStream_t stream) {
+    if (B.total_read_bytes <= 0) return hipSuccess;
+    int64_t blocks = (B.total_read_bytes + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(validate_quals, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, B);
+    return hipGetLastError();
+}
+
+}  // namespace pairhmm_hip

@@ -1,0 +1,164 @@
+/*
+ * C-ABI of the MI355X (gfx950) PairHMM engine: libgatk_pairhmm_hip.so.
+ *
+ * These entry points are what a native PairHMM implementation of GATK 3.x binds: one
+ * opaque handle per Java PairHMM instance, the batch call that replaces
+ * PairHMM.computeLikelihoods, and the region / close hooks the reference reserves for JNI
+ * back ends.  Citations are file:line under
+ *   public/gatk-utils/src/main/java/org/broadinstitute/gatk/utils/pairhmm/
+ * of the reference tree.  Plain pointers and sizes only; all byte arrays are caller-owned
+ * and are not retained after a call returns (except through the explicit resident API).
+ *
+ * Every function returns one of the GATK_PAIRHMM_* codes; the three *_ILLEGAL_* /
+ * *_INDEX_* codes stand for the Java exception the reference would have thrown at the same
+ * point.  gatk_pairhmm_last_error() returns the message for the calling thread.
+ *
+ * Threading: distinct handles may be used from distinct threads concurrently (the reference
+ * creates one PairHMM per map thread, PairHMM.java:297).  One handle must not be used from
+ * two threads at once.
+ */
+#ifndef GATK_PAIRHMM_H
+#define GATK_PAIRHMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GATK_PAIRHMM_OK 0
+#define GATK_PAIRHMM_ILLEGAL_ARGUMENT 1    /* IllegalArgumentException (PairHMM.java:105-106,272-279; PairHMMModel.java:136-138) */
+#define GATK_PAIRHMM_ILLEGAL_STATE 2       /* IllegalStateException (PairHMM.java:271,292-295) */
+#define GATK_PAIRHMM_INDEX_OUT_OF_BOUNDS 3 /* ArrayIndexOutOfBoundsException: base quality 255 (QualityUtils.java:63,173) */
+#define GATK_PAIRHMM_DEVICE_ERROR 4        /* a HIP runtime call failed, or no gfx950 device */
+#define GATK_PAIRHMM_OUT_OF_MEMORY 5
+
+typedef struct gatk_pairhmm gatk_pairhmm;                   /* one PairHMM instance bound to one GPU */
+typedef struct gatk_pairhmm_resident gatk_pairhmm_resident; /* a set of region batches kept in HBM */
+
+/*
+ * One computeLikelihoods call: the reads of one sample in one active region against the
+ * haplotypes of that region (PairHMM.java:190-214).  Each of the five per-read arrays is the
+ * concatenation of the reads' byte[] (getReadBases, getBaseQualities,
+ * getBaseInsertionQualities, getBaseDeletionQualities, the GCP map entry); read r occupies
+ * [read_offsets[r], read_offsets[r+1]).  Haplotype a occupies hap_bases[hap_offsets[a] ..
+ * hap_offsets[a+1]).  Quality bytes are used unsigned; insertion/deletion/GCP values >= 128
+ * are the Java "negative byte" error and base quality 255 is the out-of-bounds error.
+ */
+typedef struct gatk_pairhmm_batch {
+    int32_t num_reads;
+    int32_t num_haps;
+    const uint8_t* read_bases;
+    const uint8_t* read_quals;
+    const uint8_t* ins_gop;
+    const uint8_t* del_gop;
+    const uint8_t* gcp;
+    const int32_t* read_offsets; /* num_reads + 1 entries */
+    const uint8_t* hap_bases;
+    const int32_t* hap_offsets;  /* num_haps + 1 entries */
+} gatk_pairhmm_batch;
+
+/* Counters of the last compute call on a handle. */
+typedef struct gatk_pairhmm_stats {
+    int64_t pairs;          /* (read, haplotype) pairs scored */
+    int64_t cells;          /* sum of readLen * hapLen over those pairs */
+    int64_t wave_tasks;     /* wavefront work items launched in fp32 */
+    int64_t rerun_tasks;    /* of those, recomputed in fp64 because a pair fell under the fp32 threshold */
+    int64_t rerun_pairs;    /* pairs covered by the recomputed work items */
+    double fp32_kernel_ms;  /* device time of the fp32 forward kernels (HIP events), 0 if not timed */
+    double fp64_kernel_ms;  /* device time of the fp64 rerun kernels (HIP events), 0 if not timed */
+} gatk_pairhmm_stats;
+
+/* Constructor of a PairHMM instance on GPU `device` (replaces the JNI library's one-time
+ * set-up, recalled upstream as jniInitializeClassFieldsAndMachineMask).  Fails with
+ * GATK_PAIRHMM_DEVICE_ERROR when the device is absent: there is no CPU fallback. */
+int gatk_pairhmm_create(int device, gatk_pairhmm** out);
+
+/* PairHMM.initialize(int readMaxLength, int haplotypeMaxLength), PairHMM.java:104-119.
+ * ILLEGAL_ARGUMENT when either is <= 0.  Pre-sizes device buffers; optional, because
+ * compute re-initialises when a batch exceeds the current maxima (PairHMM.java:200-201). */
+int gatk_pairhmm_initialize(gatk_pairhmm* h, int32_t read_max_length, int32_t haplotype_max_length);
+
+/* PairHMM.computeLikelihoods, PairHMM.java:190-236 (upstream JNI: jniComputeLikelihoods).
+ * likelihoods[r * num_haps + a] = log10 P(read r | haplotype a): the read-major order of
+ * mLikelihoodArray (PairHMM.java:206,225).  num_reads == 0 is a no-op (PairHMM.java:193).
+ * Values are <= 0, never NaN, and may be -infinity (PairHMM.java:292-295). */
+int gatk_pairhmm_compute_likelihoods(gatk_pairhmm* h, const gatk_pairhmm_batch* batch, double* likelihoods);
+
+/* The same call with the per-read / per-haplotype byte[] passed as pointer arrays, the shape
+ * the upstream JNI holder classes (JNIReadDataHolderClass / JNIHaplotypeDataHolderClass) have. */
+int gatk_pairhmm_compute_likelihoods_ptrs(gatk_pairhmm* h, int32_t num_reads, int32_t num_haps,
+                                          const uint8_t* const* read_bases, const uint8_t* const* read_quals,
+                                          const uint8_t* const* ins_gop, const uint8_t* const* del_gop,
+                                          const uint8_t* const* gcp, const int32_t* read_lengths,
+                                          const uint8_t* const* hap_bases, const int32_t* hap_lengths,
+                                          double* likelihoods);
+
+/* Many computeLikelihoods calls (regions x samples) in one device pass: what the concurrent
+ * map threads of the reference (nanoScheduler/NanoScheduler.java:112) would each submit, batched
+ * so that small regions fill the GPU.  likelihoods[k] receives region k's read-major array. */
+int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
+                                 double* const* likelihoods);
+
+/* PairHMM.subComputeReadLikelihoodGivenHaplotypeLog10 for a single pair (PairHMM.java:313-321)
+ * through the checks of computeReadLikelihoodGivenHaplotypeLog10 (PairHMM.java:262-306). */
+int gatk_pairhmm_compute_pair(gatk_pairhmm* h, const uint8_t* hap_bases, int32_t hap_length,
+                              const uint8_t* read_bases, const uint8_t* read_quals, const uint8_t* ins_gop,
+                              const uint8_t* del_gop, const uint8_t* gcp, int32_t read_length, double* likelihood);
+
+/* BatchPairHMM.batchAdd / batchGetResult, BatchPairHMM.java:33-40: queue one read against a
+ * haplotype list, then fetch all queued results (haplotype-minor per queued read) and clear the
+ * queue.  *results points into handle-owned memory valid until the next call on the handle. */
+int gatk_pairhmm_batch_add(gatk_pairhmm* h, int32_t num_haps, const uint8_t* const* hap_bases,
+                           const int32_t* hap_lengths, const uint8_t* read_bases, const uint8_t* read_quals,
+                           const uint8_t* ins_gop, const uint8_t* del_gop, const uint8_t* gcp, int32_t read_length);
+int gatk_pairhmm_batch_get_result(gatk_pairhmm* h, const double** results, int64_t* count);
+
+/* PairHMM.getLikelihoodArray(), PairHMM.java:360: the read-major array of the last
+ * compute_likelihoods call; handle-owned. */
+int gatk_pairhmm_get_likelihood_array(gatk_pairhmm* h, const double** array, int64_t* count);
+
+/* PairHMM.finalizeRegion(), PairHMM.java:124: end of a region; drops per-region state. */
+int gatk_pairhmm_finalize_region(gatk_pairhmm* h);
+
+/* PairHMM.close(), PairHMM.java:364 (upstream JNI: jniClose): frees the handle and its
+ * device memory. */
+int gatk_pairhmm_close(gatk_pairhmm* h);
+
+/* PairHMM.setNumberOfThreads, PairHMM.java:350-355: profiling (HIP-event kernel timing in the
+ * stats) is kept only when num_threads == 1. */
+int gatk_pairhmm_set_number_of_threads(int32_t num_threads);
+
+int gatk_pairhmm_get_stats(gatk_pairhmm* h, gatk_pairhmm_stats* out);
+const char* gatk_pairhmm_last_error(void);
+const char* gatk_pairhmm_version(void);
+int gatk_pairhmm_device_count(int32_t* count);
+
+/* Engine tunables (all optional).  name: "fp32_threshold" (default 1e-28: a pair whose scaled
+ * fp32 sum falls below it is recomputed in fp64), "force_rows_per_lane" (0 = automatic),
+ * "force_fp64" (1 = score everything in fp64), "timing" (1 = fill the *_kernel_ms stats). */
+int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value);
+
+/*
+ * Resident API: keep region batches in HBM across calls, score them without touching host
+ * memory, and fetch results separately.  This is the path whose device time is the GCUPS
+ * figure (inputs already resident when the clock starts).
+ *   upload   : validate shapes, plan wave tasks, copy bytes and plan to the device
+ *   compute  : enqueue validation + forward kernels (+ fp64 rerun) on the handle's stream;
+ *              returns without waiting unless sync != 0
+ *   download : wait, check the device-side error word, copy region k's likelihoods out
+ */
+int gatk_pairhmm_upload(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
+                        gatk_pairhmm_resident** out);
+int gatk_pairhmm_compute_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, int32_t sync);
+int gatk_pairhmm_download(gatk_pairhmm* h, gatk_pairhmm_resident* r, double* const* likelihoods);
+int gatk_pairhmm_resident_free(gatk_pairhmm* h, gatk_pairhmm_resident* r);
+/* The HIP stream (hipStream_t) the handle enqueues on, for callers that time it with events. */
+int gatk_pairhmm_get_stream(gatk_pairhmm* h, void** stream);
+/* Device pointer to the resident likelihood array (all regions concatenated, region-major). */
+int gatk_pairhmm_resident_device_output(gatk_pairhmm_resident* r, void** device_ptr, int64_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GATK_PAIRHMM_H */

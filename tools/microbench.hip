@@ -1,0 +1,121 @@
+// Micro-measurements that size the PairHMM kernel design on gfx950:
+//  (1) does v_mov_b32_dpp wave_shr:1 move lane l-1 -> lane l across all 64 lanes?
+//  (2) issue rate of v_fma_f32 vs v_pk_fma_f32 vs v_fma_f64 at 1..8 waves per SIMD
+//  (3) issue rate of a dependent v_mov_dpp + fma chain (the anti-diagonal hand-off)
+// Build: hipcc --offload-arch=gfx950 -O3 tools/microbench.hip -o tools/microbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+
+__device__ inline float shr1(float v, float old) {
+    int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, r);
+}
+
+__global__ void k_dpp_check(float* out) {
+    float v = (float)threadIdx.x;
+    out[threadIdx.x] = shr1(v, -1.0f);
+}
+
+typedef float float2_ __attribute__((ext_vector_type(2)));
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_rate(float* out, int iters, float a, float b) {
+    float x0 = threadIdx.x * 1e-3f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    if (MODE == 0) {  // 8 independent v_fma_f32 chains
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); x3 = __builtin_fmaf(x3, a, b);
+                x4 = __builtin_fmaf(x4, a, b); x5 = __builtin_fmaf(x5, a, b); x6 = __builtin_fmaf(x6, a, b); x7 = __builtin_fmaf(x7, a, b);
+            }
+        }
+    } else if (MODE == 1) {  // 4 independent v_pk_fma_f32 chains (8 floats)
+        float2_ p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7}, av = {a, a}, bv = {b, b};
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(av), "v"(bv));
+            }
+        }
+        x0 = p0.x + p0.y; x1 = p1.x + p1.y; x2 = p2.x + p2.y; x3 = p3.x + p3.y;
+    } else if (MODE == 2) {  // 8 independent v_fma_f64 chains
+        double d0 = x0, d1 = x1, d2 = x2, d3 = x3, d4 = x4, d5 = x5, d6 = x6, d7 = x7, da = a, db = b;
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                d0 = __builtin_fma(d0, da, db); d1 = __builtin_fma(d1, da, db); d2 = __builtin_fma(d2, da, db); d3 = __builtin_fma(d3, da, db);
+                d4 = __builtin_fma(d4, da, db); d5 = __builtin_fma(d5, da, db); d6 = __builtin_fma(d6, da, db); d7 = __builtin_fma(d7, da, db);
+            }
+        }
+        x0 = (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
+    } else if (MODE == 3) {  // per "instruction": dpp shift then a dependent fma, 4 independent chains
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                x0 = __builtin_fmaf(shr1(x0, 0.f), a, b); x1 = __builtin_fmaf(shr1(x1, 0.f), a, b);
+                x2 = __builtin_fmaf(shr1(x2, 0.f), a, b); x3 = __builtin_fmaf(shr1(x3, 0.f), a, b);
+            }
+        }
+    } else if (MODE == 4) {  // one dependent chain of v_fma_f32 (latency)
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int u = 0; u < 64; u++) x0 = __builtin_fmaf(x0, a, b);
+        }
+    } else if (MODE == 5) {  // 8 independent chains of v_mul + v_cndmask (select-heavy mix)
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                x0 = (x1 > b ? a : b) * x0; x1 = (x2 > b ? a : b) * x1; x2 = (x3 > b ? a : b) * x2; x3 = (x0 > b ? a : b) * x3;
+            }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+}
+
+template <int MODE>
+static int run_rate(const char* name, double instr_per_iter, double flop_per_instr, float* d_out) {
+    int dev_cus = 256;
+    for (int wavesPerSimd = 1; wavesPerSimd <= 8; wavesPerSimd *= 2) {
+        int blocks = dev_cus * wavesPerSimd;  // 256 threads = 4 waves = 1 wave per SIMD per block
+        int iters = 20000;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_rate<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, 100, 0.999f, 0.001f);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_rate<MODE>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 0.999f, 0.001f);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        double waves = (double)blocks * 4;
+        double winstr = waves * iters * instr_per_iter;           // wave-instructions
+        double per_simd_per_s = winstr / (1024.0) / (ms * 1e-3);  // wave-instr per SIMD per second
+        double cyc_per_instr = 2.4e9 / per_simd_per_s;            // at nominal 2.4 GHz
+        printf("%-28s waves/SIMD=%d  %.3f ms  %.2f cyc/wave-instr(@2.4GHz)  %.1f TFLOP/s\n", name, wavesPerSimd, ms,
+               cyc_per_instr, winstr * 64 * flop_per_instr / (ms * 1e-3) / 1e12);
+    }
+    return 0;
+}
+
+int main() {
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s  CUs=%d  clock=%d kHz  LDS/block=%zu\n", prop.name, prop.multiProcessorCount, prop.clockRate, prop.sharedMemPerBlock);
+    float* d_out; CK(hipMalloc(&d_out, sizeof(float) * 256 * 8 * 256));
+    hipLaunchKernelGGL(k_dpp_check, dim3(1), dim3(64), 0, 0, d_out);
+    std::vector<float> h(64); CK(hipMemcpy(h.data(), d_out, 64 * 4, hipMemcpyDeviceToHost));
+    int ok = (h[0] == -1.0f);
+    for (int i = 1; i < 64; i++) ok &= (h[i] == (float)(i - 1));
+    printf("dpp wave_shr:1 %s  (lane0=%g lane1=%g lane16=%g lane32=%g lane63=%g)\n", ok ? "OK" : "WRONG", h[0], h[1], h[16], h[32], h[63]);
+    if (run_rate<0>("v_fma_f32 x8 indep", 64, 2, d_out)) return 1;
+    if (run_rate<1>("v_pk_fma_f32 x4 indep", 32, 4, d_out)) return 1;
+    if (run_rate<2>("v_fma_f64 x8 indep", 64, 2, d_out)) return 1;
+    if (run_rate<3>("dpp_shr1+fma x4 indep", 64, 1, d_out)) return 1;
+    if (run_rate<4>("v_fma_f32 dependent chain", 64, 2, d_out)) return 1;
+    if (run_rate<5>("cmp+cndmask+mul x4", 96, 1.0 / 3, d_out)) return 1;
+    printf("done\n");
+    return 0;
+}
