@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""PairHMM GCUPS benchmark.
+
+A step is one pass of the hot path over one synthetic batch that is already resident in HBM:
+input validation, the fp32 forward kernel and the fp64 rerun of underflowing work items, all
+enqueued through the C-ABI (gatk_pairhmm_compute_resident).  The default workload is the
+large-batch configuration the GCUPS metric is quoted on: 4096 reads x 64 haplotypes, 151 bp /
+600 bp.  With N GPUs every rank scores its own batch of that shape (pairs are independent:
+no data-path collective), so scaling is weak and value = N * cells / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_CELL = 12          # 8 mul + 4 add of the linear-space three-state recurrence
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X: 256 CU x 4 SIMD x 32 lanes x 2 FLOP x 2.4 GHz
+
+
+def cpu_baseline(batch, target_seconds=12.0):
+    """The CPU oracle's linear-space forward pass (OpenMP over reads) on a bounded sample of the
+    same workload, on this host's cores."""
+    from oracle import oracle as O
+
+    threads = max(1, min(16, os.cpu_count() or 1))
+    probe = batch.read_slice(0, min(batch.num_reads, 4 * threads))
+    t0 = time.perf_counter()
+    rc, _ = O.compute_likelihoods(probe, O.LOGLESS, fast_threads=threads)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    assert rc == 0
+    rate = probe.cells / dt
+    n = int(min(batch.num_reads, max(probe.num_reads, target_seconds * rate / (batch.cells / batch.num_reads))))
+    n = max(threads, n - n % threads)
+    sample = batch.read_slice(0, n)
+    t0 = time.perf_counter()
+    rc, _ = O.compute_likelihoods(sample, O.LOGLESS, fast_threads=threads)
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    return {"value": round(sample.cells / dt / 1e9, 4), "unit": "GCUPS", "cores": threads, "kind": "port",
+            "sample": f"first {n} of {batch.num_reads} reads x {batch.num_haps} haplotypes of the same batch "
+                      f"({sample.cells:.3e} cells, {dt:.1f} s), fp64 linear-space oracle, OpenMP over reads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=4096)
+    ap.add_argument("--haps", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the PairHMM engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from gatk_amd import synth
+    from gatk_amd.pairhmm import HipLoglessPairHMM
+
+    # every rank scores a batch of the same shape (different seed): weak scaling
+    batch = synth.config_c3(seed=synth.DEFAULT_SEED + rank, num_reads=args.reads, num_haps=args.haps)
+    hmm = HipLoglessPairHMM(local_rank)
+    hmm.set_option("timing", 1)
+    res = hmm.upload([batch])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res.compute(sync=True)
+    fp32_ms = fp64_ms = 0.0
+    rerun_pairs = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res.compute(sync=True)
+        st = hmm.stats()
+        fp32_ms += st["fp32_kernel_ms"]
+        fp64_ms += st["fp64_kernel_ms"]
+        rerun_pairs += st["rerun_pairs"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([float(batch.cells)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total_cells = float(c.item())
+    else:
+        total_cells = float(batch.cells)
+
+    # sanity: results of the last step are finite log10 likelihoods <= 0
+    out = res.download()[0]
+    assert out.shape == (batch.num_reads, batch.num_haps) and bool((out <= 0).all())
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        kern_s = fp32_ms / steps * 1e-3
+        achieved = batch.cells * FLOP_PER_CELL / kern_s / 1e12
+        line = {
+            "metric": "PairHMM GCUPS", "value": round(total_cells * steps / elapsed / 1e9, 2), "unit": "GCUPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"large-batch PairHMM: {args.reads} reads x {args.haps} haplotypes, 151 bp / 600 bp, per GPU",
+                       "cells_per_gpu_step": batch.cells, "pairs_per_gpu_step": batch.num_reads * batch.num_haps,
+                       "parallelism": f"independent batches on {world} GPU(s), host gather, no collective"},
+            "roofline": {"bound": "valu", "bound_detail": "fp32 vector ALU (a recurrence: neither HBM- nor MFMA-bound)",
+                         "kernel": "fwd_direct<float>", "achieved": round(achieved, 2), "peak": PEAK_FP32_VALU_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
+                         "flop_per_cell": FLOP_PER_CELL, "kernel_ms": round(fp32_ms / steps, 4),
+                         "kernel_gcups": round(batch.cells / kern_s / 1e9, 1)},
+            "fp64_rerun": {"pairs_per_step": rerun_pairs // steps, "rate": round(rerun_pairs / steps / (batch.num_reads * batch.num_haps), 6),
+                           "kernel_ms": round(fp64_ms / steps, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(batch)
+        print(json.dumps(line), flush=True)
+    res.free()
+    hmm.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,317 @@
+"""Parity of the HIP engine with the CPU oracle, through the C-ABI, on a real MI355X.
+
+Tolerance: |log10 lk (engine) - log10 lk (fp64 linear-space oracle)| <= 1e-3 absolute, the bound
+stated for the path (fp32 evaluation with an fp64 rerun below the underflow threshold).  -infinity
+must match exactly.  Where the engine is forced to fp64 the bound is 1e-9.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from gatk_amd import pairhmm, sharding, synth
+from gatk_amd.batch import Batch, pack
+from gatk_amd.pairhmm import ReadLikelihoodsMatrix
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pairhmm_golden.npz")
+
+
+def ref(oracle, b, threads=8):
+    rc, out = oracle.compute_likelihoods(b, oracle.LOGLESS, fast_threads=threads)
+    assert rc == 0
+    return out
+
+
+def assert_parity(got, want, tol=TOL):
+    assert got.shape == want.shape
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin), "-infinity pattern differs"
+    assert not np.isnan(got).any()
+    assert (got <= 0).all()
+    if fin.any():
+        err = np.abs(got[fin] - want[fin]).max()
+        assert err <= tol, f"max |d log10 lk| = {err}"
+
+
+def test_closed_form_known_answers(hmm):
+    b = pack([("A", [30], [45], [45], [10])], ["A", "C", "AC"])
+    got = hmm.compute_batch(b)
+    np.testing.assert_allclose(got[0], [-0.0461920023, -3.5228787453, -0.3470771124], atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["c1_slice", "c5_slice", "uniform_quals", "ragged", "wildcards"])
+def test_golden_fixtures(hmm, name):
+    z = np.load(GOLDEN)
+    b = Batch(*[z[f"{name}.{f}"] for f in ("read_bases", "read_quals", "ins_gop", "del_gop", "gcp", "read_offsets", "hap_bases", "hap_offsets")])
+    assert_parity(hmm.compute_batch(b), z[f"{name}.expected_logless"])
+
+
+def test_config_c1_full(hmm, oracle):
+    b = synth.config_c1()
+    got = hmm.compute_batch(b)
+    assert_parity(got, ref(oracle, b))
+    st = hmm.stats()
+    assert st["pairs"] == 128 * 16 and st["cells"] == b.cells
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_every_rows_per_lane_variant(hmm, oracle, k):
+    # reads of 1..60 bases (k = 1 needs <= 64 rows); every lane-segment packing is exercised
+    b = synth.make_batch(40, 5, 60, 130, seed=30 + k, len_jitter=59, gop_model="random")
+    want = ref(oracle, b)
+    hmm.set_option("force_rows_per_lane", k)
+    try:
+        assert_parity(hmm.compute_batch(b), want)
+    finally:
+        hmm.set_option("force_rows_per_lane", 0)
+
+
+def test_long_read_indel_stress_uses_the_fp64_rerun(hmm, oracle):
+    b = synth.config_c5(num_reads=96, num_haps=8)
+    got = hmm.compute_batch(b)
+    st = hmm.stats()
+    assert_parity(got, ref(oracle, b))
+    assert st["rerun_tasks"] > 0, "this workload is meant to push pairs under the fp32 threshold"
+
+
+def test_threshold_sweep(hmm, oracle):
+    """The rerun branch is data dependent: force it for every pair (threshold = +inf -> all fp64) and
+    for none that the default would not take, and require both to meet the bound."""
+    b = synth.config_c5(seed=77, num_reads=48, num_haps=6)
+    want = ref(oracle, b)
+    try:
+        hmm.set_option("fp32_threshold", 3e38)
+        all64 = hmm.compute_batch(b)
+        assert hmm.stats()["rerun_tasks"] == hmm.stats()["wave_tasks"]
+        assert_parity(all64, want, tol=1e-9)
+        hmm.set_option("fp32_threshold", 1e-28)
+        default = hmm.compute_batch(b)
+        assert_parity(default, want)
+        assert np.abs(default - all64)[np.isfinite(want)].max() <= TOL
+    finally:
+        hmm.set_option("fp32_threshold", 1e-28)
+
+
+def test_forced_fp64_matches_oracle_closely(hmm, oracle):
+    b = synth.make_batch(32, 6, 151, 420, seed=41, gop_model="random")
+    hmm.set_option("force_fp64", 1)
+    try:
+        assert_parity(hmm.compute_batch(b), ref(oracle, b), tol=1e-9)
+    finally:
+        hmm.set_option("force_fp64", 0)
+
+
+def test_underflow_to_minus_infinity(hmm, oracle):
+    b = pack([("A" * 400, [93] * 400, [93] * 400, [93] * 400, [93] * 400), ("ACGT" * 20, [30] * 80, None, None, None)],
+             ["C" * 400, "ACGT" * 30])
+    got = hmm.compute_batch(b)
+    want = ref(oracle, b, threads=1)
+    assert want[0, 0] == -np.inf
+    assert_parity(got, want)
+
+
+def test_wildcards_and_case(hmm, oracle):
+    # read 'N' and haplotype 'N' match everything; comparison is on raw bytes (Log10PairHMM.java:156)
+    reads = [("ACNTNACGTA", [30, 2, 40, 0, 11, 25, 254, 33, 7, 60], [45] * 10, [40] * 10, [10] * 10),
+             ("NNNN", [20] * 4, None, None, None), ("acgt", [20] * 4, None, None, None), ("ACGT", [20] * 4, None, None, None)]
+    with_n = pack(reads, ["ACGTNACGTAAC", "NNNNNNNN", "ACGT", "acgtacgt"])
+    assert_parity(hmm.compute_batch(with_n), ref(oracle, with_n, 1))
+    without_n = pack(reads, ["ACGTAACGTAAC", "ACGT", "acgtacgt"])
+    assert_parity(hmm.compute_batch(without_n), ref(oracle, without_n, 1))
+
+
+def test_shapes_at_the_edges(hmm, oracle):
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    def seq(n):
+        return acgt[rng.integers(0, 4, n)]
+    cases = [
+        pack([(seq(1), [30], None, None, None)], [seq(1)]),                       # 1 x 1
+        pack([(seq(1), [30], None, None, None)], [seq(700)]),                     # one row, long haplotype
+        pack([(seq(200), [25] * 200, None, None, None)], [seq(3)]),               # haplotype shorter than read
+        pack([(seq(64), [30] * 64, None, None, None), (seq(65), [30] * 65, None, None, None)], [seq(90)]),  # 64 / 65 rows
+        pack([(seq(512), rng.integers(10, 40, 512), None, None, None)], [seq(600), seq(513)]),  # longest read
+        pack([(seq(33), [30] * 33, None, None, None)] * 70, [seq(50)] * 3),       # many equal reads: several groups
+    ]
+    for b in cases:
+        assert_parity(hmm.compute_batch(b), ref(oracle, b, 1))
+
+
+def test_zero_length_read_and_empty_batch(hmm, oracle):
+    b = pack([("ACGT", [30] * 4, None, None, None), ("", [], [], [], []), ("GG", [30] * 2, None, None, None)], ["ACGTA", "CC"])
+    got = hmm.compute_batch(b)
+    assert_parity(got, ref(oracle, b, 1))
+    assert (got[1] == -np.inf).all()
+    # no reads: computeLikelihoods returns at once (PairHMM.java:193)
+    empty = pack([], ["ACGT"])
+    assert hmm.compute_batch(empty).shape == (0, 1)
+
+
+def test_error_conventions(hmm):
+    ok = ("ACGT", [30] * 4, [45] * 4, [45] * 4, [10] * 4)
+    for k in (2, 3, 4):  # negative Java byte in ins / del / gcp (PairHMMModel.java:136-138)
+        rec = list(ok)
+        rec[k] = [45, 45, 200, 45]
+        with pytest.raises(pairhmm.IllegalArgumentException):
+            hmm.compute_batch(pack([tuple(rec)], ["ACGTA"]))
+    rec = list(ok)
+    rec[1] = [30, 255, 30, 30]  # QualityUtils.java:63,173
+    with pytest.raises(pairhmm.ArrayIndexOutOfBoundsException):
+        hmm.compute_batch(pack([tuple(rec)], ["ACGTA"]))
+    rec[1] = [30, 254, 30, 30]
+    assert np.isfinite(hmm.compute_batch(pack([tuple(rec)], ["ACGTA"]))).all()
+    with pytest.raises(pairhmm.IllegalArgumentException):  # READ_MAX_LENGTH must be > 0 (PairHMM.java:105)
+        hmm.compute_batch(pack([("", [], [], [], [])], ["ACGT"]))
+    with pytest.raises(pairhmm.IllegalArgumentException):  # HAPLOTYPE_MAX_LENGTH must be > 0 (PairHMM.java:106)
+        hmm.compute_batch(pack([ok], []))
+    with pytest.raises(pairhmm.IllegalArgumentException):  # zero-length haplotype: undefined in the reference
+        hmm.compute_batch(pack([ok], ["ACGT", ""]))
+    with pytest.raises(pairhmm.IllegalArgumentException):  # read longer than the engine's maximum
+        hmm.compute_batch(pack([("A" * 513, [30] * 513, None, None, None)], ["ACGT"]))
+    with pytest.raises(pairhmm.IllegalArgumentException):
+        hmm.initialize(0, 10)
+    with pytest.raises(pairhmm.IllegalArgumentException):
+        hmm.initialize(10, -1)
+    # the handle still works after errors
+    assert np.isfinite(hmm.compute_batch(pack([ok], ["ACGTA"]))).all()
+
+
+def test_single_pair_entry_point(oracle):
+    h = pairhmm.HipLoglessPairHMM(0)
+    try:
+        args = (b"ACGTTGCA", b"ACGTGCA", [30] * 7, [45] * 7, [45] * 7, [10] * 7)
+        with pytest.raises(pairhmm.IllegalStateException):  # PairHMM.java:271
+            h.computeReadLikelihoodGivenHaplotypeLog10(*args)
+        h.initialize(7, 8)
+        got = h.computeReadLikelihoodGivenHaplotypeLog10(*args)
+        want = ref(oracle, pack([(args[1], args[2], args[3], args[4], args[5])], [args[0]]), 1)[0, 0]
+        assert abs(got - want) <= TOL
+        with pytest.raises(pairhmm.IllegalArgumentException):  # PairHMM.java:273
+            h.computeReadLikelihoodGivenHaplotypeLog10(b"ACGTTGCAA", *args[1:])
+        with pytest.raises(pairhmm.IllegalArgumentException):  # PairHMM.java:275
+            h.computeReadLikelihoodGivenHaplotypeLog10(args[0], b"ACGTGCAA", [30] * 8, [45] * 8, [45] * 8, [10] * 8)
+        with pytest.raises(pairhmm.IllegalArgumentException):  # PairHMM.java:276
+            h.computeReadLikelihoodGivenHaplotypeLog10(args[0], args[1], [30] * 6, *args[3:])
+    finally:
+        h.close()
+
+
+def test_compute_likelihoods_fills_matrix_and_array(hmm, oracle):
+    reads = [("ACGTACGTAC", [30] * 10, None, None), ("TTGCA", [25] * 5, [40] * 5, [41] * 5), ("GGGGGGG", [35] * 7, None, None)]
+    haps = ["ACGTACGTACGT", "TTGCATTGCA"]
+    m = ReadLikelihoodsMatrix(haps, reads)
+    hmm.computeLikelihoods(m, reads, gcp={0: [10] * 10, 1: [12] * 5, 2: [10] * 7})
+    b = pack([(r[0], r[1], r[2], r[3], g) for r, g in zip(reads, ([10] * 10, [12] * 5, [10] * 7))], haps)
+    want = ref(oracle, b, 1)
+    assert m.values.shape == (2, 3)  # [allele][read], ReadLikelihoods.java:1638-1640
+    assert_parity(m.values.T.copy(), want)
+    flat = hmm.getLikelihoodArray()  # read-major, PairHMM.java:206,225
+    assert flat.shape == (6,) and np.array_equal(flat.reshape(3, 2), m.values.T)
+    assert m.get(1, 2) == m.values[1, 2]
+    hmm.computeLikelihoods(ReadLikelihoodsMatrix(haps, []), [])  # no-op
+    hmm.finalizeRegion()
+
+
+def test_batch_pair_hmm_interface(hmm, oracle):
+    haps = [b"ACGTACGTACGT", b"TTGCATTGCA", b"ACGTAC"]
+    r1 = (b"ACGTACG", [30] * 7, [45] * 7, [45] * 7, [10] * 7)
+    r2 = (b"TTGCA", [20] * 5, [40] * 5, [40] * 5, [10] * 5)
+    hmm.batchAdd(haps, *r1)
+    hmm.batchAdd(haps[:2], *r2)
+    got = hmm.batchGetResult()
+    want = np.concatenate([ref(oracle, pack([r1], haps), 1)[0], ref(oracle, pack([r2], haps[:2]), 1)[0]])
+    assert got.shape == (5,) and np.abs(got - want).max() <= TOL
+    assert hmm.batchGetResult().shape == (0,)  # queue was cleared
+
+
+def test_pointer_array_entry_point(hmm, oracle):
+    b = synth.make_batch(9, 4, 50, 100, seed=8, len_jitter=30)
+    lib = pairhmm.load_library()
+    nr, nh = b.num_reads, b.num_haps
+    def ptrs(arr, offs):
+        a = np.ascontiguousarray(arr)
+        return a, (C.c_void_p * (len(offs) - 1))(*[a.ctypes.data + int(o) for o in offs[:-1]])
+    keep = [ptrs(x, b.read_offsets) for x in (b.read_bases, b.read_quals, b.ins_gop, b.del_gop, b.gcp)]
+    hp = ptrs(b.hap_bases, b.hap_offsets)
+    rl, hl = np.diff(b.read_offsets).astype(np.int32), np.diff(b.hap_offsets).astype(np.int32)
+    out = np.empty((nr, nh))
+    rc = lib.gatk_pairhmm_compute_likelihoods_ptrs(hmm._h, nr, nh, keep[0][1], keep[1][1], keep[2][1], keep[3][1], keep[4][1],
+                                                   rl.ctypes.data, hp[1], hl.ctypes.data, out.ctypes.data)
+    assert rc == 0
+    assert_parity(out, ref(oracle, b, 1))
+
+
+def test_many_regions_in_one_pass(hmm, oracle):
+    regions = synth.make_regions(24, seed=11, coverage=8, read_len=100)
+    regions.insert(5, pack([], ["ACGT"]))  # a region without reads is skipped
+    outs = hmm.compute_regions(regions)
+    assert len(outs) == len(regions)
+    for b, o in zip(regions, outs):
+        if b.num_reads:
+            assert_parity(o, ref(oracle, b))
+    res = hmm.upload(regions)
+    try:
+        res.compute(sync=True)
+        for o, o2 in zip(outs, res.download()):
+            if o.size:
+                np.testing.assert_array_equal(o, o2)
+    finally:
+        res.free()
+
+
+def test_sharded_regions_single_rank(hmm, oracle):
+    regions = synth.make_regions(6, seed=12, coverage=6, read_len=80)
+    outs = sharding.compute_sharded(regions, hmm.compute_regions, rank=0, world=1)
+    for b, o in zip(regions, outs):
+        assert_parity(o, ref(oracle, b))
+    big = synth.make_batch(40, 4, 90, 200, seed=13)
+    assert_parity(sharding.compute_split_batch(big, hmm.compute_regions), ref(oracle, big))
+
+
+def test_long_haplotype_and_length_cap(hmm, oracle):
+    rng = np.random.default_rng(6)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    hap = acgt[rng.integers(0, 4, 16000)]
+    read = hap[5000:5100].copy()
+    b = pack([(read, [30] * 100, None, None, None)], [hap])
+    assert_parity(hmm.compute_batch(b), ref(oracle, b, 1))
+    with pytest.raises(pairhmm.IllegalArgumentException):
+        hmm.compute_batch(pack([(read, [30] * 100, None, None, None)], [acgt[rng.integers(0, 4, 16001)]]))
+
+
+def test_full_size_large_batch_properties(hmm, oracle):
+    """4096 x 64, 151 bp / 600 bp (the benchmark workload), checked without scoring all of it on the
+    CPU: (a) a random sample of reads against every haplotype vs the oracle; (b) read order does not
+    change any value (pairs are independent, packing must not leak between lane segments);
+    (c) every value is a finite log10 probability; (d) the resident path returns the same bits."""
+    b = synth.config_c3()
+    assert b.num_reads == 4096 and b.num_haps == 64 and b.cells == 4096 * 151 * 64 * 600
+    got = hmm.compute_batch(b)
+    st = hmm.stats()
+    assert np.isfinite(got).all() and (got <= 0).all()
+    rng = np.random.default_rng(99)
+    pick = np.sort(rng.choice(b.num_reads, size=48, replace=False))
+    sub = subset_reads(b, pick)
+    assert_parity(got[pick], ref(oracle, sub))
+    perm = rng.permutation(b.num_reads)
+    shuffled = hmm.compute_batch(subset_reads(b, perm))
+    np.testing.assert_array_equal(shuffled, got[perm])
+    res = hmm.upload([b])
+    try:
+        res.compute(sync=True)
+        np.testing.assert_array_equal(res.download()[0], got)
+    finally:
+        res.free()
+    assert st["rerun_pairs"] / st["pairs"] < 0.01
+
+
+def subset_reads(b, idx):
+    parts = [slice(int(b.read_offsets[i]), int(b.read_offsets[i + 1])) for i in idx]
+    cat = lambda a: np.concatenate([a[p] for p in parts])
+    offs = np.zeros(len(idx) + 1, np.int32)
+    offs[1:] = np.cumsum([p.stop - p.start for p in parts])
+    return Batch(cat(b.read_bases), cat(b.read_quals), cat(b.ins_gop), cat(b.del_gop), cat(b.gcp), offs, b.hap_bases, b.hap_offsets)

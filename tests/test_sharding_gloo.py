@@ -1,0 +1,69 @@
+"""The N > 1 path on CPU: two processes (gloo) each score their share of a region stream and of
+one large batch, rank 0 gathers on the host.  The per-rank compute is the CPU oracle here (no
+GPU in this tier); on the GPU box the same functions are driven with the HIP engine
+(tests/test_gpu_parity.py::test_sharded_regions_single_rank)."""
+import os
+import socket
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gatk_amd import sharding, synth
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_compute(batches):
+    from oracle import oracle as O
+    outs = []
+    for b in batches:
+        rc, o = O.compute_likelihoods(b, O.LOGLESS, fast_threads=1)
+        assert rc == 0
+        outs.append(o)
+    return outs
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        regions = synth.make_regions(9, seed=21, coverage=6, read_len=60)
+        got = sharding.compute_sharded(regions, _oracle_compute, rank, world)
+        big = synth.make_batch(23, 3, 40, 90, seed=22, len_jitter=15)
+        whole = sharding.compute_split_batch(big, _oracle_compute, rank, world)
+        if rank == 0:
+            q.put((got, whole))
+        else:
+            assert got is None and whole is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, whole = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    regions = synth.make_regions(9, seed=21, coverage=6, read_len=60)
+    want = _oracle_compute(regions)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+    big = synth.make_batch(23, 3, 40, 90, seed=22, len_jitter=15)
+    np.testing.assert_array_equal(whole, _oracle_compute([big])[0])
+    # both ranks had work
+    shards = sharding.shard_regions(regions, world)
+    assert all(len(s) > 0 for s in shards)
