@@ -136,12 +136,12 @@ namespace {
 
 // Rows per lane for a region: minimise modelled issue slots, keeping enough waves in flight.
 int choose_rows_per_lane(int max_read_len, int64_t num_reads, int64_t num_haps, double mean_hap_len, int forced) {
-    const int min_k = (max_read_len + kWave - 1) / kWave;
+    const int min_k = (max_read_len + kWave) / kWave;  // lanes * k >= len + 1
     if (forced >= min_k && forced <= kMaxRowsPerLane) return forced;
     int best_k = std::max(min_k, 1);
     double best = std::numeric_limits<double>::infinity();
     for (int k = std::max(min_k, 1); k <= kMaxRowsPerLane; ++k) {
-        const int lanes = (max_read_len + k - 1) / k;
+        const int lanes = (max_read_len + k) / k;
         const int per_wave = std::max(1, kWave / lanes);
         const double tasks = std::ceil(static_cast<double>(num_reads) / per_wave) * static_cast<double>(num_haps);
         const double steps = mean_hap_len + lanes - 1;
@@ -179,9 +179,9 @@ int check_region(const gatk_pairhmm_batch& b, int k) {
     for (int a = 0; a < b.num_haps; ++a)
         if (b.hap_offsets[a + 1] - b.hap_offsets[a] == 0)
             return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("zero-length haplotype: the reference result is undefined") + where);
-    if (read_max > kWave * kMaxRowsPerLane)
+    if (read_max > kWave * kMaxRowsPerLane - 1)
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "readBases is too long, got " + std::to_string(read_max) + " but max is " +
-                                                       std::to_string(kWave * kMaxRowsPerLane) + where);
+                                                       std::to_string(kWave * kMaxRowsPerLane - 1) + where);
     return GATK_PAIRHMM_OK;
 }
 
@@ -272,7 +272,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             while (pos < order.size()) {
                 const int r = order[pos];
                 const int len = b.read_offsets[r + 1] - b.read_offsets[r];
-                const int seg = (len + K - 1) / K;
+                const int seg = (len + K) / K;  // rows >= len + 1: every segment starts with a pad row
                 if (used + seg > kWave) break;
                 const int pad_top = seg * K - len;
                 for (int t = 0; t < seg; ++t) {

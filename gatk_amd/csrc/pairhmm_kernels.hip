@@ -15,7 +15,8 @@
 //   * the only values that cross lanes are, for the lane's LAST row, what the next read row
 //     needs from it: Sn = M*t0' + (I + D)*t1' (the bracket of the next row's M one column later)
 //     and In = M*t2' + I*t3' (the next row's I in this column), primed = next row's transitions.
-//     Both move one lane up with a single v_mov_b32_dpp wave_shr:1 each per step;
+//     Both move one lane up with a single v_mov_b32_dpp wave_shr:1 each per step (fp32 carries
+//     them in a rescaled form, see Rows);
 //   * the rows inside a lane hand the same two values down through registers;
 //   * haplotype bases sit in an LDS image private to the wave; per-row constants (prior for
 //     match / mismatch, six transitions) are expanded once per task from the read's quality bytes
@@ -64,22 +65,38 @@ __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(double& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(unsigned& x) { asm volatile("" : "+v"(x)); }
 
-// Registers of one lane: K read rows.
-//   E  = D / matchToDeletion of the row (so the deletion recurrence is one fma: E' = M + E*t5)
-//   Sd = hand-off Sn of the row above, one column back (the bracket of this row's M)
+// Registers of one lane: K read rows.  Two arithmetic forms share the layout:
+//
+// plain (fp64):  E = D / t4 (deletion recurrence is one fma), hand-offs Sn and In as in the header.
+//
+// scaled (fp32): every quantity that is only ever multiplied by a per-row constant is carried
+//   divided by that constant, so that the constant disappears from the inner loop:
+//     E  = D / t4                        E'  = M + E * t5
+//     F  = I / t2                        Fn  = M + F * cF,  cF = t2 * t3' / t2'      (next row's F)
+//     Sn = bracket of next row's M / t0' Sn  = M + F * cI + E * cE,
+//                                        cI = t2 * t1' / t0',  cE = t4 * t1' / t0'
+//     M  = prior * t0 * Sd               (t0 folded into the row's two prior constants)
+//   7 vector instructions per cell (compare, select, mul, 4 fma).  A row with t0 = 0 (insertion and
+//   deletion quality both <= 3) makes cI / cE infinite; the NaN that follows reaches the final
+//   sum, fails the threshold test and sends the task to the plain fp64 pass.
 template <typename T, int K>
 struct Rows {
     unsigned XB[K];
-    T P[K], Q[K], T5[K], T0N[K], T1N[K], T2N[K], T3N[K], T41N[K];
+    T P[K], Q[K], T5[K];
+    T A[K], B[K], C[K], D[K], E[K];  // plain: t0', t1', t2', t3', t4*t1'   scaled: cF, cI, cE, -, -
     T Ml[K], El[K], Sd[K];
+    T T2L;   // scaled: t2 of the lane's last row (I = F * t2 in the final sum)
     T Sout, Iout, acc;
 };
+
+template <typename T> struct IsScaled { static constexpr bool value = false; };
+template <> struct IsScaled<float> { static constexpr bool value = true; };
 
 // One haplotype column for all K rows of the lane.  Sin / Iin: hand-off of the row above the
 // lane's first row in this column.
 template <typename T, int K, bool HAPN>
 __device__ __forceinline__ void column(Rows<T, K>& w, const unsigned yb, const T Sin, const T Iin) {
-    T Iup = Iin;    // I of the current row in this column
+    T Iup = Iin;    // I (plain) or F (scaled) of the current row in this column
     T Snext = Sin;  // Sn of the row above in this column: next column's diagonal term
 #pragma unroll
     for (int r = 0; r < K; ++r) {
@@ -88,9 +105,16 @@ __device__ __forceinline__ void column(Rows<T, K>& w, const unsigned yb, const T
         const T prior = match ? w.P[r] : w.Q[r];
         const T M = prior * w.Sd[r];
         const T E = fma_(w.El[r], w.T5[r], w.Ml[r]);
-        const T In = fma_(M, w.T2N[r], Iup * w.T3N[r]);
-        const T Sn = fma_(E, w.T41N[r], fma_(Iup, w.T1N[r], M * w.T0N[r]));
-        if (r == K - 1) w.acc += M + Iup;
+        T In, Sn;
+        if (IsScaled<T>::value) {
+            In = fma_(Iup, w.A[r], M);
+            Sn = fma_(E, w.C[r], fma_(Iup, w.B[r], M));
+            if (r == K - 1) w.acc = fma_(Iup, w.T2L, w.acc + M);
+        } else {
+            In = fma_(M, w.C[r], Iup * w.D[r]);
+            Sn = fma_(E, w.E[r], fma_(Iup, w.B[r], M * w.A[r]));
+            if (r == K - 1) w.acc += M + Iup;
+        }
         w.Ml[r] = M;
         w.El[r] = E;
         w.Sd[r] = Snext;
@@ -104,6 +128,7 @@ __device__ __forceinline__ void column(Rows<T, K>& w, const unsigned yb, const T
 template <typename T, int K, bool HAPN>
 __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_idx, unsigned char* slice,
                                          const int lane, const bool queue_underflow) {
+    constexpr bool kScaled = IsScaled<T>::value;
     const Task tk = B.tasks[task_idx];
     const int H = B.hap_len[tk.hap];
     const int fill = B.group_fill[tk.group];
@@ -118,6 +143,9 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     }
 
     // ---- per-row constants ---------------------------------------------------------------------
+    // Every segment starts with at least one pad row.  A pad row behaves as matrix row 0
+    // (M = I = 0, D = scale / H in every column) whatever the lane above hands down, so the value
+    // a segment's first lane receives from the previous segment never reaches a real row.
     const T initD = static_cast<T>(::ldexp(1.0, Scale<T>::kExp2) / static_cast<double>(H));
     int ro = 0, R = 0;
     if (ld.read_idx >= 0) {
@@ -125,64 +153,76 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
         R = B.read_off[ld.read_idx + 1] - ro;
     }
     Rows<T, K> w;
+    w.T2L = static_cast<T>(0);
 #pragma unroll
     for (int r = 0; r < K; ++r) {
-        const int i = ld.first_row + r;  // 1-based read row
-        double p = 0, q = 0, t4 = 0, t5 = 0, t0n = 0, t1n = 0, t2n = 0, t3n = 0;
-        bool pad = false;
+        const int i = ld.first_row + r;  // 1-based read row; <= 0: pad row
+        double p = 0, q = 0, t0 = 1, t2 = 0, t4 = 0, t5 = 0, t0n = 0, t1n = 0, t2n = 0, t3n = 0;
+        bool pad = false, has_next = false;
         unsigned xb = kNoBase;
         if (ld.read_idx >= 0) {
             if (i >= 1) {
                 const unsigned x = B.read_bases[ro + i - 1];
                 const double e = B.err_prob[B.read_quals[ro + i - 1]];
+                const unsigned ins = B.ins_gop[ro + i - 1] & 127u, del = B.del_gop[ro + i - 1] & 127u;
                 xb = x;
-                p = 1.0 - e;                             // QualityUtils.qualToProb
-                q = (x == 'N') ? p : e / 3.0;            // a read 'N' matches every base
-                t4 = B.err_prob[B.del_gop[ro + i - 1]];  // matchToDeletion
-                t5 = B.err_prob[B.gcp[ro + i - 1]];      // deletionToDeletion
+                p = 1.0 - e;                         // QualityUtils.qualToProb
+                q = (x == 'N') ? p : e / 3.0;        // a read 'N' matches every base
+                t0 = B.match_to_match[ins * 128u + del];
+                t2 = B.err_prob[ins];                // matchToInsertion
+                t4 = B.err_prob[del];                // matchToDeletion
+                t5 = B.err_prob[B.gcp[ro + i - 1]];  // deletionToDeletion
             } else {
-                // leading pad row: behaves as matrix row 0 (M = I = 0, D = scale / H in every column)
                 pad = true;
                 t4 = 1.0;
                 t5 = 1.0;
-                if (i < 0) t1n = 1.0;
+                if (i < 0) { t0n = 1.0; t1n = 1.0; }  // next row is a pad row too: anything finite
             }
             if (i >= 0 && i < R) {  // transitions of read row i+1, taken from quals[i]
                 const unsigned ins = B.ins_gop[ro + i] & 127u, del = B.del_gop[ro + i] & 127u;
                 const double eg = B.err_prob[B.gcp[ro + i]];
-                t1n = 1.0 - eg;  // indelToMatch
-                if (i >= 1) {
-                    t0n = B.match_to_match[ins * 128u + del];
-                    t2n = B.err_prob[ins];  // matchToInsertion
-                    t3n = eg;               // insertionToInsertion
-                }
+                has_next = true;
+                t0n = B.match_to_match[ins * 128u + del];
+                t1n = 1.0 - eg;          // indelToMatch
+                t2n = B.err_prob[ins];   // matchToInsertion
+                t3n = eg;                // insertionToInsertion
             }
         }
         w.XB[r] = xb;
-        w.P[r] = static_cast<T>(p); w.Q[r] = static_cast<T>(q);
         w.T5[r] = static_cast<T>(t5);
-        w.T0N[r] = static_cast<T>(t0n); w.T1N[r] = static_cast<T>(t1n);
-        w.T2N[r] = static_cast<T>(t2n); w.T3N[r] = static_cast<T>(t3n);
-        w.T41N[r] = static_cast<T>(t4 * t1n);
+        if (kScaled) {
+            w.P[r] = static_cast<T>(p * t0);
+            w.Q[r] = static_cast<T>(q * t0);
+            const bool real_next = has_next && i >= 1;
+            w.A[r] = static_cast<T>(real_next ? t2 * t3n / t2n : 0.0);
+            w.B[r] = static_cast<T>(real_next ? t2 * t1n / t0n : 0.0);
+            w.C[r] = static_cast<T>((has_next || pad) ? t4 * t1n / t0n : 0.0);
+            if (r == K - 1) w.T2L = static_cast<T>(t2);
+            pin(w.A[r]); pin(w.B[r]); pin(w.C[r]);
+        } else {
+            const bool real_next = has_next && i >= 1;
+            w.P[r] = static_cast<T>(p);
+            w.Q[r] = static_cast<T>(q);
+            w.A[r] = static_cast<T>(real_next ? t0n : 0.0);
+            w.B[r] = static_cast<T>(t1n);
+            w.C[r] = static_cast<T>(real_next ? t2n : 0.0);
+            w.D[r] = static_cast<T>(real_next ? t3n : 0.0);
+            w.E[r] = static_cast<T>(t4 * t1n);
+            pin(w.A[r]); pin(w.B[r]); pin(w.C[r]); pin(w.D[r]); pin(w.E[r]);
+        }
         w.Ml[r] = static_cast<T>(0);
         w.El[r] = pad ? initD : static_cast<T>(0);  // column 0
-        pin(w.XB[r]); pin(w.P[r]); pin(w.Q[r]); pin(w.T5[r]); pin(w.T0N[r]); pin(w.T1N[r]);
-        pin(w.T2N[r]); pin(w.T3N[r]); pin(w.T41N[r]);
+        pin(w.XB[r]); pin(w.P[r]); pin(w.Q[r]); pin(w.T5[r]);
     }
+    pin(w.T2L);
     // column-0 hand-offs: Sn of the row above, where M = I = 0
+    const T* cS = kScaled ? w.C : w.E;
 #pragma unroll
-    for (int r = 1; r < K; ++r) w.Sd[r] = w.El[r - 1] * w.T41N[r - 1];
-    w.Sout = w.El[K - 1] * w.T41N[K - 1];
+    for (int r = 1; r < K; ++r) w.Sd[r] = w.El[r - 1] * cS[r - 1];
+    w.Sout = w.El[K - 1] * cS[K - 1];
     w.Iout = static_cast<T>(0);
     w.acc = static_cast<T>(0);
-    const bool seg_start = ld.seg_lane == 0;
-    // what matrix row 0 hands to read row 1: Sn = (scale / H) * indelToMatch(row 1), In = 0
-    T s_inject = static_cast<T>(0);
-    if (ld.read_idx >= 0 && seg_start && R > 0) s_inject = initD * static_cast<T>(1.0 - B.err_prob[B.gcp[ro]]);
-    {
-        const T up = shr1(w.Sout);
-        w.Sd[0] = seg_start ? s_inject : up;
-    }
+    w.Sd[0] = shr1(w.Sout);
 
     // ---- anti-diagonal sweep -------------------------------------------------------------------
     // step s: the lane at segment position t works on haplotype column s - t (0-based).
@@ -190,13 +230,10 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     //   [fill, H)            every lane of every segment is inside 0..H-1      -> no mask
     //   [max(H, fill), H+fill) pipeline drain: lanes with s - t >= H are done  -> masked
     const unsigned char* hp = slice + (kHapFrontPad - ld.seg_lane);
-    const T zero = static_cast<T>(0);
     __builtin_amdgcn_wave_barrier();
     auto masked_step = [&](const int s) {
-        T Sin = shr1(w.Sout);
-        T Iin = shr1(w.Iout);
-        Sin = seg_start ? s_inject : Sin;
-        Iin = seg_start ? zero : Iin;
+        const T Sin = shr1(w.Sout);
+        const T Iin = shr1(w.Iout);
         const unsigned yb = hp[s];
         if (static_cast<unsigned>(s - ld.seg_lane) < static_cast<unsigned>(H)) column<T, K, HAPN>(w, yb, Sin, Iin);
     };
@@ -211,10 +248,8 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
             n0 = hp[s + 4]; n1 = hp[s + 5]; n2 = hp[s + 6]; n3 = hp[s + 7];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                T Sin = shr1(w.Sout);
-                T Iin = shr1(w.Iout);
-                Sin = seg_start ? s_inject : Sin;
-                Iin = seg_start ? zero : Iin;
+                const T Sin = shr1(w.Sout);
+                const T Iin = shr1(w.Iout);
                 column<T, K, HAPN>(w, u == 0 ? y0 : u == 1 ? y1 : u == 2 ? y2 : y3, Sin, Iin);
             }
         }
@@ -226,7 +261,8 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     if (ld.seg_last != 0 && ld.read_idx >= 0) {
         const double res = ::log10(static_cast<double>(w.acc)) - Scale<T>::kExp2 * 0.30102999566398119521;
         B.out[B.read_out_base[ld.read_idx] + B.hap_local[tk.hap]] = res;
-        if (std::is_same<T, float>::value) under = !(static_cast<float>(w.acc) >= B.fp32_threshold);
+        // too small for fp32 to be trusted, or NaN / infinity from the scaled form: redo in fp64
+        if (kScaled) under = !(static_cast<float>(w.acc) >= B.fp32_threshold && static_cast<float>(w.acc) <= 3.0e38f);
     }
     if (queue_underflow) {
         if (__any(under ? 1 : 0)) {
