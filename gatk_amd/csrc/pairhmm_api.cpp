@@ -19,8 +19,9 @@
 #include "pairhmm_tables.h"
 
 namespace pairhmm_hip {
-hipError_t launch_forward(const DeviceBatch& B, int rows_per_lane, bool hap_has_n, bool fp64, bool list_mode,
+hipError_t launch_forward(const DeviceBatch& B, int rows_per_lane, int emit_mode, bool fp64, bool list_mode,
                           int blocks, hipStream_t stream);
+int lds_bytes_per_wave(int rows_per_lane, int emit_mode, int max_hap_len);
 hipError_t launch_validate(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_fill_neg_inf(double* out, const int32_t* idx, int n, hipStream_t stream);
 }  // namespace pairhmm_hip
@@ -72,8 +73,9 @@ struct Bucket {
     int rows_per_lane = 0;
     int task_begin = 0;  // offset into the task array
     int num_tasks = 0;
-    int lds_per_wave = 0;
-    bool hap_has_n = false;
+    int max_hap_len = 0;
+    int emit_mode = kEmitCompare;     // fp32 pass
+    int emit_mode_fp64 = kEmitCompare;  // fp64 pass: always compares bytes
 };
 
 }  // namespace
@@ -114,6 +116,7 @@ struct gatk_pairhmm {
     int max_read = 0, max_hap = 0;
     float fp32_threshold = 1e-28f;
     int force_rows_per_lane = 0;
+    int emit_mode = -1;  // -1: table when the haplotype alphabet allows it; 0: always compare bytes
     bool force_fp64 = false;
     bool timing = false;
     gatk_pairhmm_resident scratch;  // buffers reused by the host-pointer entry points
@@ -137,16 +140,18 @@ namespace {
 // Rows per lane for a region: minimise modelled issue slots, keeping enough waves in flight.
 int choose_rows_per_lane(int max_read_len, int64_t num_reads, int64_t num_haps, double mean_hap_len, int forced) {
     const int min_k = (max_read_len + kWave) / kWave;  // lanes * k >= len + 1
-    if (forced >= min_k && forced <= kMaxRowsPerLane) return forced;
-    int best_k = std::max(min_k, 1);
+    if (forced >= min_k && rows_per_lane_supported(forced)) return forced;
+    int best_k = kMaxRowsPerLane;
     double best = std::numeric_limits<double>::infinity();
-    for (int k = std::max(min_k, 1); k <= kMaxRowsPerLane; ++k) {
+    for (int k : kRowsPerLaneChoices) {
+        if (k < min_k) continue;
+        if (k > 10 && best_k != kMaxRowsPerLane) break;  // beyond 10 rows the fp64 rerun kernel spills: only for long reads
         const int lanes = (max_read_len + k) / k;
         const int per_wave = std::max(1, kWave / lanes);
         const double tasks = std::ceil(static_cast<double>(num_reads) / per_wave) * static_cast<double>(num_haps);
         const double steps = mean_hap_len + lanes - 1;
-        const double slots = steps * (10.0 * k + 10.0);          // VALU instructions per task
-        const double in_flight = std::min(tasks, 2048.0);        // 2 waves on each of 1024 SIMDs saturate issue
+        const double slots = steps * (6.0 * k + 6.0);      // vector instructions per task
+        const double in_flight = std::min(tasks, 2048.0);  // two waves on each of the 1024 SIMDs saturate issue
         const double t = tasks * slots / in_flight;
         if (t < best * 0.98) { best = t; best_k = k; }
     }
@@ -206,8 +211,8 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     std::vector<int32_t> read_off{0}, read_out_base, hap_off, hap_len, hap_local, group_fill;
     std::vector<LaneDesc> lanes;
     std::vector<std::vector<Task>> tasks_by_k(kMaxRowsPerLane + 1);
-    std::vector<int> lds_by_k(kMaxRowsPerLane + 1, 0);
-    bool any_hap_n = false;
+    std::vector<int> hap_max_by_k(kMaxRowsPerLane + 1, 0);
+    bool any_hap_n = false, any_hap_other = false;
     int64_t cells = 0, pairs = 0;
     int read_max_all = 0, hap_max_all = 0;
 
@@ -228,7 +233,11 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             hap_local.push_back(a);
             hap_pool.insert(hap_pool.end(), b.hap_bases + o, b.hap_bases + o + len);
             hap_pool.resize((hap_pool.size() + 15) & ~size_t{15}, 0);
-            if (!any_hap_n && memchr(b.hap_bases + o, 'N', len)) any_hap_n = true;
+            for (int x = 0; x < len; ++x) {
+                const uint8_t c = b.hap_bases[o + x];
+                if (c == 'N') any_hap_n = true;
+                else if (c != 'A' && c != 'C' && c != 'G' && c != 'T') any_hap_other = true;
+            }
             hap_total += len;
             hap_max = std::max(hap_max, len);
         }
@@ -292,8 +301,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         const int last_group = static_cast<int>(group_fill.size());
         for (int a = 0; a < nh; ++a)
             for (int g = first_group; g < last_group; ++g) tasks_by_k[K].push_back(Task{g, hap_base_idx + a});
-        const int lds = (kHapFrontPad + ((hap_max + 3) & ~3) + kWave + 8 + 15) & ~15;
-        lds_by_k[K] = std::max(lds_by_k[K], lds);
+        hap_max_by_k[K] = std::max(hap_max_by_k[K], hap_max);
     }
     if (hap_max_all > 16000) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "Haplotype bases is too long, got " + std::to_string(hap_max_all) + " but max is 16000");
 
@@ -315,8 +323,14 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         bk.rows_per_lane = K;
         bk.task_begin = static_cast<int>(R->tasks.size());
         bk.num_tasks = static_cast<int>(tv.size());
-        bk.lds_per_wave = lds_by_k[K];
-        bk.hap_has_n = any_hap_n;
+        bk.max_hap_len = hap_max_by_k[K];
+        bk.emit_mode_fp64 = any_hap_n ? kEmitCompareN : kEmitCompare;
+        bk.emit_mode = bk.emit_mode_fp64;
+        if (!any_hap_other && h->emit_mode != 0) {
+            const int lut = any_hap_n ? kEmitLut5 : kEmitLut4;
+            // the table must leave room for at least one workgroup per CU (64 KiB dynamic LDS per block)
+            if (lds_bytes_per_wave(K, lut, bk.max_hap_len) * kWavesPerBlock <= 64 * 1024) bk.emit_mode = lut;
+        }
         R->tasks.insert(R->tasks.end(), tv.begin(), tv.end());
         R->buckets.push_back(bk);
     }
@@ -354,7 +368,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
 }
 
 // counters layout: [0] error word, [1 + b] rerun count of bucket b
-constexpr int kMaxBuckets = kMaxRowsPerLane;
+constexpr int kMaxBuckets = kMaxRowsPerLane;  // one bucket per rows-per-lane value in use
 
 int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     HIP_TRY(hipSetDevice(h->device));
@@ -395,9 +409,10 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
         L.num_tasks = bk.num_tasks;
         L.rerun_count = R->d_counters.as<int32_t>() + 1 + bi;
         L.rerun_list = R->d_rerun_lists.as<int32_t>() + bk.task_begin;
-        L.lds_per_wave = bk.lds_per_wave;
+        const int mode = h->force_fp64 ? bk.emit_mode_fp64 : bk.emit_mode;
+        L.lds_per_wave = lds_bytes_per_wave(bk.rows_per_lane, mode, bk.max_hap_len);
         const int blocks = (bk.num_tasks + kWavesPerBlock - 1) / kWavesPerBlock;
-        HIP_TRY(launch_forward(L, bk.rows_per_lane, bk.hap_has_n, h->force_fp64, false, blocks, s));
+        HIP_TRY(launch_forward(L, bk.rows_per_lane, mode, h->force_fp64, false, blocks, s));
     }
     if (timing) HIP_TRY(hipEventRecord(R->ev[1], s));
     if (!h->force_fp64) {
@@ -408,9 +423,9 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
             L.num_tasks = bk.num_tasks;
             L.rerun_count = R->d_counters.as<int32_t>() + 1 + bi;
             L.rerun_list = R->d_rerun_lists.as<int32_t>() + bk.task_begin;
-            L.lds_per_wave = bk.lds_per_wave;
+            L.lds_per_wave = lds_bytes_per_wave(bk.rows_per_lane, bk.emit_mode_fp64, bk.max_hap_len);
             const int blocks = std::min((bk.num_tasks + kWavesPerBlock - 1) / kWavesPerBlock, 1024);
-            HIP_TRY(launch_forward(L, bk.rows_per_lane, bk.hap_has_n, true, true, blocks, s));
+            HIP_TRY(launch_forward(L, bk.rows_per_lane, bk.emit_mode_fp64, true, true, blocks, s));
         }
     }
     if (timing) HIP_TRY(hipEventRecord(R->ev[2], s));
@@ -695,6 +710,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
     if (n == "fp32_threshold") h->fp32_threshold = static_cast<float>(value);
     else if (n == "force_rows_per_lane") h->force_rows_per_lane = static_cast<int>(value);
     else if (n == "force_fp64") h->force_fp64 = value != 0;
+    else if (n == "emit_mode") h->emit_mode = static_cast<int>(value);
     else if (n == "timing") h->timing = value != 0;
     else return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "unknown option " + n);
     return GATK_PAIRHMM_OK;

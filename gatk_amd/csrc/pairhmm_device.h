@@ -4,11 +4,26 @@
 
 namespace pairhmm_hip {
 
-// Number of read rows a lane can own (template instantiations of the forward kernel).
-constexpr int kMaxRowsPerLane = 8;
+// Read rows a lane can own: the template instantiations of the forward kernel.
+constexpr int kMaxRowsPerLane = 16;
+constexpr int kRowsPerLaneChoices[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16};
+inline bool rows_per_lane_supported(int k) {
+    for (int c : kRowsPerLaneChoices)
+        if (c == k) return true;
+    return false;
+}
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
-constexpr int kHapFrontPad = 64;  // bytes in front of the LDS haplotype image: lanes ahead of column 1 read here
+constexpr int kHapFrontPad = 64;  // entries in front of the LDS haplotype image: lanes ahead of column 1 read here
+constexpr int kHapBackPad = 80;   // entries behind it: draining lanes and the read-ahead of the sweep land here
+
+// How a cell gets its emission term prior[i][j].
+enum EmitMode : int {
+    kEmitCompare = 0,   // compare read byte with haplotype byte (any alphabet)
+    kEmitCompareN = 1,  // same, and a haplotype 'N' matches everything
+    kEmitLut4 = 2,      // haplotypes are A/C/G/T only: per-wave LDS table indexed by base code
+    kEmitLut5 = 3,      // haplotypes are A/C/G/T/N only: table with an 'N' column
+};
 
 // One lane of a wave-group.  A wave-group packs one or more reads into the 64 lanes of a
 // wavefront: a read of length R takes ceil(R/K) consecutive lanes ("segment"), each lane owning K

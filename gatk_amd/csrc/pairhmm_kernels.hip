@@ -18,14 +18,19 @@
 //     Both move one lane up with a single v_mov_b32_dpp wave_shr:1 each per step (fp32 carries
 //     them in a rescaled form, see Rows);
 //   * the rows inside a lane hand the same two values down through registers;
-//   * haplotype bases sit in an LDS image private to the wave; per-row constants (prior for
-//     match / mismatch, six transitions) are expanded once per task from the read's quality bytes
-//     through look-up tables and stay in registers;
-//   * lanes outside 1 <= column <= H are masked off, so every pair starts from exact boundary
-//     values and no pair ever reads another pair's state.
+//   * haplotype bases sit in an LDS image private to the wave; per-row transition constants are
+//     expanded once per task from the read's quality bytes through look-up tables and stay in
+//     registers;
+//   * the emission term prior[i][j] is either selected per cell by comparing bytes (any
+//     alphabet), or, when the haplotypes are made of A/C/G/T(/N) only, read from a per-wave LDS
+//     table [row][base code][lane] that the lane fills once per task: one conflict-free
+//     ds_read_b32 per cell replaces the compare + select pair on the vector ALU;
+//   * lanes outside 1 <= column <= H are masked off, and every lane segment begins with a pad
+//     row that reproduces matrix row 0, so every pair starts from exact boundary values and no
+//     pair ever reads another pair's state.
 //
-// fp32 runs with scale 2^120; a task in which some pair's final sum is below the threshold
-// is queued and recomputed by the same code in fp64 with scale 2^1020.
+// fp32 runs with scale 2^120; a task in which some pair's final sum is below the threshold (or
+// is not finite) is queued and recomputed by the same code in fp64 with scale 2^1020.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -65,6 +70,9 @@ __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(double& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(unsigned& x) { asm volatile("" : "+v"(x)); }
 
+constexpr bool is_lut(int mode) { return mode == kEmitLut4 || mode == kEmitLut5; }
+constexpr int lut_codes(int mode) { return mode == kEmitLut5 ? 5 : 4; }
+
 // Registers of one lane: K read rows.  Two arithmetic forms share the layout:
 //
 // plain (fp64):  E = D / t4 (deletion recurrence is one fma), hand-offs Sn and In as in the header.
@@ -76,34 +84,30 @@ __device__ __forceinline__ void pin(unsigned& x) { asm volatile("" : "+v"(x)); }
 //     Sn = bracket of next row's M / t0' Sn  = M + F * cI + E * cE,
 //                                        cI = t2 * t1' / t0',  cE = t4 * t1' / t0'
 //     M  = prior * t0 * Sd               (t0 folded into the row's two prior constants)
-//   7 vector instructions per cell (compare, select, mul, 4 fma).  A row with t0 = 0 (insertion and
-//   deletion quality both <= 3) makes cI / cE infinite; the NaN that follows reaches the final
-//   sum, fails the threshold test and sends the task to the plain fp64 pass.
+//   5 arithmetic instructions per cell (mul, 4 fma) plus the emission term.  A row with t0 = 0
+//   (insertion and deletion quality both <= 3) makes cI / cE infinite; the NaN that follows
+//   reaches the final sum, fails the threshold test and sends the task to the plain fp64 pass.
 template <typename T, int K>
 struct Rows {
-    unsigned XB[K];
-    T P[K], Q[K], T5[K];
+    T T5[K];
     T A[K], B[K], C[K], D[K], E[K];  // plain: t0', t1', t2', t3', t4*t1'   scaled: cF, cI, cE, -, -
     T Ml[K], El[K], Sd[K];
-    T T2L;   // scaled: t2 of the lane's last row (I = F * t2 in the final sum)
+    T T2L;  // scaled: t2 of the lane's last row (I = F * t2 in the final sum)
     T Sout, Iout, acc;
 };
 
 template <typename T> struct IsScaled { static constexpr bool value = false; };
 template <> struct IsScaled<float> { static constexpr bool value = true; };
 
-// One haplotype column for all K rows of the lane.  Sin / Iin: hand-off of the row above the
-// lane's first row in this column.
-template <typename T, int K, bool HAPN>
-__device__ __forceinline__ void column(Rows<T, K>& w, const unsigned yb, const T Sin, const T Iin) {
+// One haplotype column for all K rows of the lane.  prior[r]: emission term of row r in this
+// column; Sin / Iin: hand-off of the row above the lane's first row in this column.
+template <typename T, int K>
+__device__ __forceinline__ void column(Rows<T, K>& w, const T (&prior)[K], const T Sin, const T Iin) {
     T Iup = Iin;    // I (plain) or F (scaled) of the current row in this column
     T Snext = Sin;  // Sn of the row above in this column: next column's diagonal term
 #pragma unroll
     for (int r = 0; r < K; ++r) {
-        bool match = (yb == w.XB[r]);
-        if (HAPN) match = match || (yb == 'N');
-        const T prior = match ? w.P[r] : w.Q[r];
-        const T M = prior * w.Sd[r];
+        const T M = prior[r] * w.Sd[r];
         const T E = fma_(w.El[r], w.T5[r], w.Ml[r]);
         T In, Sn;
         if (IsScaled<T>::value) {
@@ -125,21 +129,53 @@ __device__ __forceinline__ void column(Rows<T, K>& w, const unsigned yb, const T
     w.Iout = Iup;
 }
 
-template <typename T, int K, bool HAPN>
+// LDS image of one wave.
+//   compare modes: [64 pad][haplotype bytes][pad]                       (byte per base)
+//   table modes  : [K][codes][64] emission table | [64 pad][code*256 as u16 per base][pad]
+// Base codes are (byte >> 1) & 3 (A 0, C 1, T 2, G 3) and 4 for 'N'; the host only selects a table
+// mode when every haplotype byte of the launch is one of those letters.
+template <int K, int MODE>
+struct Image {
+    static constexpr int kTableBytes = is_lut(MODE) ? K * lut_codes(MODE) * kWave * 4 : 0;
+};
+
+template <typename T, int K, int MODE>
 __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_idx, unsigned char* slice,
                                          const int lane, const bool queue_underflow) {
     constexpr bool kScaled = IsScaled<T>::value;
+    constexpr bool kLut = is_lut(MODE);
+    constexpr int kCodes = lut_codes(MODE);
+    static_assert(!kLut || std::is_same<T, float>::value, "the emission table holds floats");
     const Task tk = B.tasks[task_idx];
     const int H = B.hap_len[tk.hap];
     const int fill = B.group_fill[tk.group];
     const LaneDesc ld = B.lanes[tk.group * kWave + lane];
+    unsigned char* const hap_img = slice + Image<K, MODE>::kTableBytes;
 
     // ---- haplotype bases -> this wave's LDS image --------------------------------------------
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(B.hap_pool + B.hap_off[tk.hap]);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(slice + kHapFrontPad);
         const int words = (H + 3) >> 2;
-        for (int d = lane; d < words; d += kWave) dst[d] = src[d];
+        if (kLut) {
+            // every entry the sweep can touch must hold a valid table offset: zero the pads
+            uint16_t* img = reinterpret_cast<uint16_t*>(hap_img);
+            img[lane] = 0;
+            for (int d = lane; d < kHapBackPad; d += kWave) img[kHapFrontPad + words * 4 + d] = 0;
+            uint2* dst = reinterpret_cast<uint2*>(img + kHapFrontPad);
+            for (int d = lane; d < words; d += kWave) {
+                const uint32_t v = src[d];
+                unsigned c[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const unsigned byte = (v >> (8 * b)) & 0xffu;
+                    c[b] = ((byte == 'N' && kCodes == 5) ? 4u : ((byte >> 1) & 3u)) << 8;
+                }
+                dst[d] = make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
+            }
+        } else {
+            uint32_t* dst = reinterpret_cast<uint32_t*>(hap_img + kHapFrontPad);
+            for (int d = lane; d < words; d += kWave) dst[d] = src[d];
+        }
     }
 
     // ---- per-row constants ---------------------------------------------------------------------
@@ -153,6 +189,8 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
         R = B.read_off[ld.read_idx + 1] - ro;
     }
     Rows<T, K> w;
+    unsigned XB[K];
+    T P[K], Q[K];
     w.T2L = static_cast<T>(0);
 #pragma unroll
     for (int r = 0; r < K; ++r) {
@@ -188,21 +226,20 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
                 t3n = eg;                // insertionToInsertion
             }
         }
-        w.XB[r] = xb;
+        const bool real_next = has_next && i >= 1;
+        XB[r] = xb;
         w.T5[r] = static_cast<T>(t5);
         if (kScaled) {
-            w.P[r] = static_cast<T>(p * t0);
-            w.Q[r] = static_cast<T>(q * t0);
-            const bool real_next = has_next && i >= 1;
+            P[r] = static_cast<T>(p * t0);
+            Q[r] = static_cast<T>(q * t0);
             w.A[r] = static_cast<T>(real_next ? t2 * t3n / t2n : 0.0);
             w.B[r] = static_cast<T>(real_next ? t2 * t1n / t0n : 0.0);
             w.C[r] = static_cast<T>((has_next || pad) ? t4 * t1n / t0n : 0.0);
             if (r == K - 1) w.T2L = static_cast<T>(t2);
             pin(w.A[r]); pin(w.B[r]); pin(w.C[r]);
         } else {
-            const bool real_next = has_next && i >= 1;
-            w.P[r] = static_cast<T>(p);
-            w.Q[r] = static_cast<T>(q);
+            P[r] = static_cast<T>(p);
+            Q[r] = static_cast<T>(q);
             w.A[r] = static_cast<T>(real_next ? t0n : 0.0);
             w.B[r] = static_cast<T>(t1n);
             w.C[r] = static_cast<T>(real_next ? t2n : 0.0);
@@ -212,7 +249,17 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
         }
         w.Ml[r] = static_cast<T>(0);
         w.El[r] = pad ? initD : static_cast<T>(0);  // column 0
-        pin(w.XB[r]); pin(w.P[r]); pin(w.Q[r]); pin(w.T5[r]);
+        pin(w.T5[r]);
+        if (kLut) {
+            // emission table: entry [r][code][lane] = prior of row r against base code
+            float* tbl = reinterpret_cast<float*>(slice);
+            const unsigned letters[5] = {'A', 'C', 'T', 'G', 'N'};
+#pragma unroll
+            for (int c = 0; c < kCodes; ++c)
+                tbl[(r * kCodes + c) * kWave + lane] = static_cast<float>((xb == letters[c] || c == 4) ? P[r] : Q[r]);
+        } else {
+            pin(XB[r]); pin(P[r]); pin(Q[r]);
+        }
     }
     pin(w.T2L);
     // column-0 hand-offs: Sn of the row above, where M = I = 0
@@ -223,38 +270,98 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     w.Iout = static_cast<T>(0);
     w.acc = static_cast<T>(0);
     w.Sd[0] = shr1(w.Sout);
+    __builtin_amdgcn_wave_barrier();
 
     // ---- anti-diagonal sweep -------------------------------------------------------------------
     // step s: the lane at segment position t works on haplotype column s - t (0-based).
     //   [0, fill)            pipeline fill: lanes with s < t wait              -> masked
     //   [fill, H)            every lane of every segment is inside 0..H-1      -> no mask
     //   [max(H, fill), H+fill) pipeline drain: lanes with s - t >= H are done  -> masked
-    const unsigned char* hp = slice + (kHapFrontPad - ld.seg_lane);
-    __builtin_amdgcn_wave_barrier();
-    auto masked_step = [&](const int s) {
-        const T Sin = shr1(w.Sout);
-        const T Iin = shr1(w.Iout);
-        const unsigned yb = hp[s];
-        if (static_cast<unsigned>(s - ld.seg_lane) < static_cast<unsigned>(H)) column<T, K, HAPN>(w, yb, Sin, Iin);
-    };
     const int steady_begin = fill < H ? fill : H;
-    for (int s = 0; s < steady_begin; ++s) masked_step(s);
-    int s = steady_begin;
-    if (s + 4 <= H) {
-        unsigned n0 = hp[s], n1 = hp[s + 1], n2 = hp[s + 2], n3 = hp[s + 3];
-        for (; s + 4 <= H; s += 4) {
-            const unsigned y0 = n0, y1 = n1, y2 = n2, y3 = n3;
-            // next iteration's bases; reads past H land in the image's tail padding
-            n0 = hp[s + 4]; n1 = hp[s + 5]; n2 = hp[s + 6]; n3 = hp[s + 7];
+    int s = 0;
+    if (kLut) {
+        const uint16_t* hp = reinterpret_cast<const uint16_t*>(hap_img) + (kHapFrontPad - ld.seg_lane);
+        const unsigned char* tbl_lane = slice + lane * 4;
+        auto emit = [&](const unsigned code_off, T (&prior)[K]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const T Sin = shr1(w.Sout);
-                const T Iin = shr1(w.Iout);
-                column<T, K, HAPN>(w, u == 0 ? y0 : u == 1 ? y1 : u == 2 ? y2 : y3, Sin, Iin);
+            for (int r = 0; r < K; ++r)
+                prior[r] = *reinterpret_cast<const float*>(tbl_lane + code_off + r * kCodes * kWave * 4);
+        };
+        auto masked_step = [&](const int step) {
+            const T Sin = shr1(w.Sout);
+            const T Iin = shr1(w.Iout);
+            T prior[K];
+            emit(hp[step], prior);
+            if (static_cast<unsigned>(step - ld.seg_lane) < static_cast<unsigned>(H)) column<T, K>(w, prior, Sin, Iin);
+        };
+        for (; s < steady_begin; ++s) masked_step(s);
+        if (s + 4 <= H) {
+            // two-deep software pipeline: emission terms of the next four columns and base codes of
+            // the four after them are in flight while the current four columns are computed
+            T pc[4][K];
+            unsigned yn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) emit(hp[s + u], pc[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) yn[u] = hp[s + 4 + u];
+            for (; s + 4 <= H; s += 4) {
+                T pn[4][K];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) emit(yn[u], pn[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) yn[u] = hp[s + 8 + u];  // past H: lands in the zeroed tail pad
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const T Sin = shr1(w.Sout);
+                    const T Iin = shr1(w.Iout);
+                    column<T, K>(w, pc[u], Sin, Iin);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < K; ++r) pc[u][r] = pn[u][r];
             }
         }
+        for (; s < H + fill; ++s) masked_step(s);
+    } else {
+        const unsigned char* hp = hap_img + (kHapFrontPad - ld.seg_lane);
+        auto emit = [&](const unsigned yb, T (&prior)[K]) {
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                bool match = (yb == XB[r]);
+                if (MODE == kEmitCompareN) match = match || (yb == 'N');
+                prior[r] = match ? P[r] : Q[r];
+            }
+        };
+        auto masked_step = [&](const int step) {
+            const T Sin = shr1(w.Sout);
+            const T Iin = shr1(w.Iout);
+            const unsigned yb = hp[step];
+            if (static_cast<unsigned>(step - ld.seg_lane) < static_cast<unsigned>(H)) {
+                T prior[K];
+                emit(yb, prior);
+                column<T, K>(w, prior, Sin, Iin);
+            }
+        };
+        for (; s < steady_begin; ++s) masked_step(s);
+        if (s + 4 <= H) {
+            unsigned n0 = hp[s], n1 = hp[s + 1], n2 = hp[s + 2], n3 = hp[s + 3];
+            for (; s + 4 <= H; s += 4) {
+                const unsigned y0 = n0, y1 = n1, y2 = n2, y3 = n3;
+                // next iteration's bases; reads past H land in the image's tail padding
+                n0 = hp[s + 4]; n1 = hp[s + 5]; n2 = hp[s + 6]; n3 = hp[s + 7];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const T Sin = shr1(w.Sout);
+                    const T Iin = shr1(w.Iout);
+                    T prior[K];
+                    emit(u == 0 ? y0 : u == 1 ? y1 : u == 2 ? y2 : y3, prior);
+                    column<T, K>(w, prior, Sin, Iin);
+                }
+            }
+        }
+        for (; s < H + fill; ++s) masked_step(s);
     }
-    for (; s < H + fill; ++s) masked_step(s);
 
     // ---- termination ---------------------------------------------------------------------------
     bool under = false;
@@ -275,19 +382,19 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
 }
 
 // One task per wave, tasks taken in launch order.
-template <typename T, int K, bool HAPN>
+template <typename T, int K, int MODE>
 __global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_direct(const DeviceBatch B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & (kWave - 1);
     const int task = blockIdx.x * kWavesPerBlock + wave;
     if (task >= B.num_tasks) return;
-    run_task<T, K, HAPN>(B, task, lds + wave * B.lds_per_wave, lane, std::is_same<T, float>::value);
+    run_task<T, K, MODE>(B, task, lds + wave * B.lds_per_wave, lane, std::is_same<T, float>::value);
 }
 
 // Tasks taken from the device-side rerun list; every wave strides over the list, so the grid
 // size does not depend on the (device-only) list length and each wave leaves when the list ends.
-template <typename T, int K, bool HAPN>
+template <typename T, int K, int MODE>
 __global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_list(const DeviceBatch B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -297,7 +404,7 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_list(const DeviceBa
     const int stride = gridDim.x * kWavesPerBlock;
     for (int it = blockIdx.x * kWavesPerBlock + wave; it < n; it += stride) {
         const int task = __builtin_amdgcn_readfirstlane(B.rerun_list[it]);
-        run_task<T, K, HAPN>(B, task, lds + wave * B.lds_per_wave, lane, false);
+        run_task<T, K, MODE>(B, task, lds + wave * B.lds_per_wave, lane, false);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -322,44 +429,66 @@ __global__ void __launch_bounds__(256) fill_neg_inf(double* out, const int32_t* 
     if (k < n) out[idx[k]] = -__builtin_inf();
 }
 
-template <typename T, int K>
-hipError_t launch_k(const DeviceBatch& B, bool hapn, bool list_mode, int blocks, hipStream_t stream) {
+template <typename T, int K, int MODE>
+hipError_t launch_m(const DeviceBatch& B, bool list_mode, int blocks, hipStream_t stream) {
     const size_t lds = static_cast<size_t>(B.lds_per_wave) * kWavesPerBlock;
     const dim3 grid(blocks), block(kWave * kWavesPerBlock);
     if (list_mode) {
-        if (hapn) hipLaunchKernelGGL((fwd_list<T, K, true>), grid, block, lds, stream, B);
-        else hipLaunchKernelGGL((fwd_list<T, K, false>), grid, block, lds, stream, B);
+        // only the fp64 pass walks a rerun list
+        if constexpr (std::is_same<T, double>::value) hipLaunchKernelGGL((fwd_list<T, K, MODE>), grid, block, lds, stream, B);
+        else return hipErrorInvalidValue;
     } else {
-        if (hapn) hipLaunchKernelGGL((fwd_direct<T, K, true>), grid, block, lds, stream, B);
-        else hipLaunchKernelGGL((fwd_direct<T, K, false>), grid, block, lds, stream, B);
+        hipLaunchKernelGGL((fwd_direct<T, K, MODE>), grid, block, lds, stream, B);
     }
     return hipGetLastError();
 }
 
+template <typename T, int K>
+hipError_t launch_k(const DeviceBatch& B, int mode, bool list_mode, int blocks, hipStream_t stream) {
+    if constexpr (std::is_same<T, float>::value) {
+        if (mode == kEmitLut4) return launch_m<T, K, kEmitLut4>(B, list_mode, blocks, stream);
+        if (mode == kEmitLut5) return launch_m<T, K, kEmitLut5>(B, list_mode, blocks, stream);
+    }
+    if (mode == kEmitCompare) return launch_m<T, K, kEmitCompare>(B, list_mode, blocks, stream);
+    if (mode == kEmitCompareN) return launch_m<T, K, kEmitCompareN>(B, list_mode, blocks, stream);
+    return hipErrorInvalidValue;
+}
+
 template <typename T>
-hipError_t launch_t(const DeviceBatch& B, int K, bool hapn, bool list_mode, int blocks, hipStream_t stream) {
+hipError_t launch_t(const DeviceBatch& B, int K, int mode, bool list_mode, int blocks, hipStream_t stream) {
     switch (K) {
-        case 1: return launch_k<T, 1>(B, hapn, list_mode, blocks, stream);
-        case 2: return launch_k<T, 2>(B, hapn, list_mode, blocks, stream);
-        case 3: return launch_k<T, 3>(B, hapn, list_mode, blocks, stream);
-        case 4: return launch_k<T, 4>(B, hapn, list_mode, blocks, stream);
-        case 5: return launch_k<T, 5>(B, hapn, list_mode, blocks, stream);
-        case 6: return launch_k<T, 6>(B, hapn, list_mode, blocks, stream);
-        case 7: return launch_k<T, 7>(B, hapn, list_mode, blocks, stream);
-        case 8: return launch_k<T, 8>(B, hapn, list_mode, blocks, stream);
+        case 1: return launch_k<T, 1>(B, mode, list_mode, blocks, stream);
+        case 2: return launch_k<T, 2>(B, mode, list_mode, blocks, stream);
+        case 3: return launch_k<T, 3>(B, mode, list_mode, blocks, stream);
+        case 4: return launch_k<T, 4>(B, mode, list_mode, blocks, stream);
+        case 5: return launch_k<T, 5>(B, mode, list_mode, blocks, stream);
+        case 6: return launch_k<T, 6>(B, mode, list_mode, blocks, stream);
+        case 7: return launch_k<T, 7>(B, mode, list_mode, blocks, stream);
+        case 8: return launch_k<T, 8>(B, mode, list_mode, blocks, stream);
+        case 10: return launch_k<T, 10>(B, mode, list_mode, blocks, stream);
+        case 12: return launch_k<T, 12>(B, mode, list_mode, blocks, stream);
+        case 16: return launch_k<T, 16>(B, mode, list_mode, blocks, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
 }  // namespace
 
+// Bytes of LDS one wave needs for a launch with these parameters.
+int lds_bytes_per_wave(int rows_per_lane, int emit_mode, int max_hap_len) {
+    const int entries = kHapFrontPad + ((max_hap_len + 3) & ~3) + kHapBackPad;
+    const bool lut = is_lut(emit_mode);
+    const int table = lut ? rows_per_lane * lut_codes(emit_mode) * kWave * 4 : 0;
+    return (table + entries * (lut ? 2 : 1) + 15) & ~15;
+}
+
 // Enqueue the forward kernel for one bucket of tasks.  list_mode: take task indices from the
-// bucket's rerun list (fp64 pass) instead of 0..num_tasks-1.
-hipError_t launch_forward(const DeviceBatch& B, int rows_per_lane, bool hap_has_n, bool fp64, bool list_mode,
+// bucket's rerun list (fp64 pass) instead of 0..num_tasks-1.  The fp64 pass always compares bytes.
+hipError_t launch_forward(const DeviceBatch& B, int rows_per_lane, int emit_mode, bool fp64, bool list_mode,
                           int blocks, hipStream_t stream) {
     if (B.num_tasks <= 0 || blocks <= 0) return hipSuccess;
-    return fp64 ? launch_t<double>(B, rows_per_lane, hap_has_n, list_mode, blocks, stream)
-                : launch_t<float>(B, rows_per_lane, hap_has_n, list_mode, blocks, stream);
+    return fp64 ? launch_t<double>(B, rows_per_lane, emit_mode, list_mode, blocks, stream)
+                : launch_t<float>(B, rows_per_lane, emit_mode, list_mode, blocks, stream);
 }
 
 hipError_t launch_fill_neg_inf(double* out, const int32_t* idx, int n, hipStream_t stream) {

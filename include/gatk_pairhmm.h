@@ -136,7 +136,8 @@ int gatk_pairhmm_device_count(int32_t* count);
 
 /* Engine tunables (all optional).  name: "fp32_threshold" (default 1e-28: a pair whose scaled
  * fp32 sum falls below it is recomputed in fp64), "force_rows_per_lane" (0 = automatic),
- * "force_fp64" (1 = score everything in fp64), "timing" (1 = fill the *_kernel_ms stats). */
+ * "force_fp64" (1 = score everything in fp64), "emit_mode" (-1 = automatic, 0 = always compare bases
+ * instead of using the per-wave emission table), "timing" (1 = fill the *_kernel_ms stats). */
 int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value);
 
 /*

@@ -38,14 +38,19 @@ def main():
     hmm.set_option("force_fp64", 1)
     cmp("C1 forced fp64", hmm, synth.config_c1(), ks=(0, 5))
     hmm.set_option("force_fp64", 0)
+    hmm.set_option("emit_mode", 0)
+    cmp("C1 compare-mode", hmm, synth.config_c1(), ks=(0, 5))
+    hmm.set_option("emit_mode", -1)
 
     # resident timing on a C3 slice and full C3
     hmm.set_option("timing", 1)
-    for nreads, nhaps in ((512, 64), (4096, 64)):
+    for nreads, nhaps in ((4096, 64),):
         t0 = time.time()
         b = synth.config_c3(num_reads=nreads, num_haps=nhaps)
         t1 = time.time()
-        for k in (0, 3, 4, 5, 6, 8):
+        for k in (0, 5, 6, 7, 8, 10, 12, 16, -8):
+            hmm.set_option("emit_mode", 0 if k < 0 else -1)
+            k = abs(k)
             hmm.set_option("force_rows_per_lane", k)
             res = hmm.upload([b])
             res.compute(sync=True)
