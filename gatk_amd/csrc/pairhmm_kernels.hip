@@ -72,6 +72,11 @@ __device__ __forceinline__ void pin(unsigned& x) { asm volatile("" : "+v"(x)); }
 
 constexpr bool is_lut(int mode) { return mode == kEmitLut4 || mode == kEmitLut5; }
 constexpr int lut_codes(int mode) { return mode == kEmitLut5 ? 5 : 4; }
+// The emission table keeps two read rows side by side, [row pair][base code][lane][2], so that one
+// ds_read_b64 (conflict-free: consecutive lanes, consecutive 8-byte slots) fetches two cells' terms.
+constexpr int lut_row_pairs(int k) { return (k + 1) / 2; }
+constexpr int kLutCodeStride = kWave * 8;  // bytes between two base codes of one row pair
+constexpr int lut_table_bytes(int k, int mode) { return is_lut(mode) ? lut_row_pairs(k) * lut_codes(mode) * kLutCodeStride : 0; }
 
 // Registers of one lane: K read rows.  Two arithmetic forms share the layout:
 //
@@ -131,12 +136,12 @@ __device__ __forceinline__ void column(Rows<T, K>& w, const T (&prior)[K], const
 
 // LDS image of one wave.
 //   compare modes: [64 pad][haplotype bytes][pad]                       (byte per base)
-//   table modes  : [K][codes][64] emission table | [64 pad][code*256 as u16 per base][pad]
+//   table modes  : [K/2][codes][64][2] emission table | [64 pad][code*512 as u16 per base][pad]
 // Base codes are (byte >> 1) & 3 (A 0, C 1, T 2, G 3) and 4 for 'N'; the host only selects a table
 // mode when every haplotype byte of the launch is one of those letters.
 template <int K, int MODE>
 struct Image {
-    static constexpr int kTableBytes = is_lut(MODE) ? K * lut_codes(MODE) * kWave * 4 : 0;
+    static constexpr int kTableBytes = lut_table_bytes(K, MODE);
 };
 
 template <typename T, int K, int MODE>
@@ -168,7 +173,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const unsigned byte = (v >> (8 * b)) & 0xffu;
-                    c[b] = ((byte == 'N' && kCodes == 5) ? 4u : ((byte >> 1) & 3u)) << 8;
+                    c[b] = ((byte == 'N' && kCodes == 5) ? 4u : ((byte >> 1) & 3u)) * kLutCodeStride;
                 }
                 dst[d] = make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
             }
@@ -251,12 +256,13 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
         w.El[r] = pad ? initD : static_cast<T>(0);  // column 0
         pin(w.T5[r]);
         if (kLut) {
-            // emission table: entry [r][code][lane] = prior of row r against base code
+            // emission table: entry [r / 2][code][lane][r % 2] = prior of row r against base code
             float* tbl = reinterpret_cast<float*>(slice);
             const unsigned letters[5] = {'A', 'C', 'T', 'G', 'N'};
 #pragma unroll
             for (int c = 0; c < kCodes; ++c)
-                tbl[(r * kCodes + c) * kWave + lane] = static_cast<float>((xb == letters[c] || c == 4) ? P[r] : Q[r]);
+                tbl[(((r >> 1) * kCodes + c) * kWave + lane) * 2 + (r & 1)] =
+                    static_cast<float>((xb == letters[c] || c == 4) ? P[r] : Q[r]);
         } else {
             pin(XB[r]); pin(P[r]); pin(Q[r]);
         }
@@ -281,11 +287,14 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     int s = 0;
     if (kLut) {
         const uint16_t* hp = reinterpret_cast<const uint16_t*>(hap_img) + (kHapFrontPad - ld.seg_lane);
-        const unsigned char* tbl_lane = slice + lane * 4;
+        const unsigned char* tbl_lane = slice + lane * 8;
         auto emit = [&](const unsigned code_off, T (&prior)[K]) {
 #pragma unroll
-            for (int r = 0; r < K; ++r)
-                prior[r] = *reinterpret_cast<const float*>(tbl_lane + code_off + r * kCodes * kWave * 4);
+            for (int g = 0; g < lut_row_pairs(K); ++g) {
+                const float2 v = *reinterpret_cast<const float2*>(tbl_lane + code_off + g * kCodes * kLutCodeStride);
+                prior[2 * g] = v.x;
+                if (2 * g + 1 < K) prior[2 * g + 1] = v.y;
+            }
         };
         auto masked_step = [&](const int step) {
             const T Sin = shr1(w.Sout);
@@ -478,7 +487,7 @@ hipError_t launch_t(const DeviceBatch& B, int K, int mode, bool list_mode, int b
 int lds_bytes_per_wave(int rows_per_lane, int emit_mode, int max_hap_len) {
     const int entries = kHapFrontPad + ((max_hap_len + 3) & ~3) + kHapBackPad;
     const bool lut = is_lut(emit_mode);
-    const int table = lut ? rows_per_lane * lut_codes(emit_mode) * kWave * 4 : 0;
+    const int table = lut_table_bytes(rows_per_lane, emit_mode);
     return (table + entries * (lut ? 2 : 1) + 15) & ~15;
 }
 

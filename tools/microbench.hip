@@ -73,6 +73,33 @@ __global__ void __launch_bounds__(256) k_rate(float* out, int iters, float a, fl
             }
         }
     }
+    else if (MODE == 6) {  // 8 independent v_fma_f32 chains, all three operands in VGPRs
+        float y0 = x0 * 0.5f, y1 = x1 * 0.5f, y2 = x2 * 0.5f, y3 = x3 * 0.5f, z0 = a + x0, z1 = a + x1, z2 = b + x2, z3 = b + x3;
+        asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3));
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                x0 = __builtin_fmaf(x0, y0, z0); x1 = __builtin_fmaf(x1, y1, z1); x2 = __builtin_fmaf(x2, y2, z2); x3 = __builtin_fmaf(x3, y3, z3);
+                x4 = __builtin_fmaf(x4, y0, z1); x5 = __builtin_fmaf(x5, y1, z2); x6 = __builtin_fmaf(x6, y2, z3); x7 = __builtin_fmaf(x7, y3, z0);
+            }
+        }
+    } else if (MODE == 7) {  // the cell pattern: M = p*s; E = fma(E,c,Mo); F = fma(F,a,M); S = fma(E,c2,fma(F,b,M)), 4 independent cells
+        float p0 = x0, p1 = x1, p2 = x2, p3 = x3, c0 = a + x4 * 1e-6f, c1 = b + x5 * 1e-6f, c2 = a * 0.5f + x6 * 1e-6f, c3 = b * 0.5f + x7 * 1e-6f;
+        float E0 = 1, E1 = 1, E2 = 1, E3 = 1, F0 = 1, F1 = 1, F2 = 1, F3 = 1, S0 = 1, S1 = 1, S2 = 1, S3 = 1, M0 = 1, M1 = 1, M2 = 1, M3 = 1;
+        asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                float m0 = p0 * S0, m1 = p1 * S1, m2 = p2 * S2, m3 = p3 * S3;
+                E0 = __builtin_fmaf(E0, c0, M0); E1 = __builtin_fmaf(E1, c1, M1); E2 = __builtin_fmaf(E2, c2, M2); E3 = __builtin_fmaf(E3, c3, M3);
+                F0 = __builtin_fmaf(F0, c1, m0); F1 = __builtin_fmaf(F1, c2, m1); F2 = __builtin_fmaf(F2, c3, m2); F3 = __builtin_fmaf(F3, c0, m3);
+                S0 = __builtin_fmaf(E0, c2, __builtin_fmaf(F0, c3, m0)); S1 = __builtin_fmaf(E1, c3, __builtin_fmaf(F1, c0, m1));
+                S2 = __builtin_fmaf(E2, c0, __builtin_fmaf(F2, c1, m2)); S3 = __builtin_fmaf(E3, c1, __builtin_fmaf(F3, c2, m3));
+                M0 = m0; M1 = m1; M2 = m2; M3 = m3;
+            }
+        }
+        x0 = S0 + E0 + F0; x1 = S1 + E1 + F1; x2 = S2 + E2 + F2; x3 = S3 + E3 + F3;
+    }
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
 }
 
@@ -116,6 +143,8 @@ int main() {
     if (run_rate<3>("dpp_shr1+fma x4 indep", 64, 1, d_out)) return 1;
     if (run_rate<4>("v_fma_f32 dependent chain", 64, 2, d_out)) return 1;
     if (run_rate<5>("cmp+cndmask+mul x4", 96, 1.0 / 3, d_out)) return 1;
+    if (run_rate<6>("v_fma_f32 x8 indep 3 VGPR ops", 64, 2, d_out)) return 1;
+    if (run_rate<7>("cell pattern 5 instr x4 cells", 80, 1.8, d_out)) return 1;
     printf("done\n");
     return 0;
 }
