@@ -138,7 +138,10 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 
 // Rows per lane for a region: minimise modelled issue slots, keeping enough waves in flight.
-int choose_rows_per_lane(int max_read_len, int64_t num_reads, int64_t num_haps, double mean_hap_len, int forced) {
+// call_pairs: (read, haplotype) pairs of the whole call, all regions together: regions share launches,
+// so whether the GPU is full is a property of the call, not of one region.
+int choose_rows_per_lane(int max_read_len, int64_t num_reads, int64_t num_haps, double mean_hap_len, int64_t call_pairs,
+                         int forced) {
     const int min_k = (max_read_len + kWave) / kWave;  // lanes * k >= len + 1
     if (forced >= min_k && rows_per_lane_supported(forced)) return forced;
     int best_k = kMaxRowsPerLane;
@@ -151,7 +154,8 @@ int choose_rows_per_lane(int max_read_len, int64_t num_reads, int64_t num_haps, 
         const double tasks = std::ceil(static_cast<double>(num_reads) / per_wave) * static_cast<double>(num_haps);
         const double steps = mean_hap_len + lanes - 1;
         const double slots = steps * (6.0 * k + 6.0);      // vector instructions per task
-        const double in_flight = std::min(tasks, 2048.0);  // two waves on each of the 1024 SIMDs saturate issue
+        // two waves on each of the 1024 SIMDs saturate issue
+        const double in_flight = std::min(std::max(tasks, static_cast<double>(call_pairs) / per_wave), 2048.0);
         const double t = tasks * slots / in_flight;
         if (t < best * 0.98) { best = t; best_k = k; }
     }
@@ -216,6 +220,9 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     int64_t cells = 0, pairs = 0;
     int read_max_all = 0, hap_max_all = 0;
 
+    int64_t call_pairs = 0;
+    for (int k = 0; k < num_regions; ++k) call_pairs += static_cast<int64_t>(regions[k].num_reads) * regions[k].num_haps;
+
     for (int k = 0; k < num_regions; ++k) {
         const gatk_pairhmm_batch& b = regions[k];
         const int nr = b.num_reads, nh = b.num_reads == 0 ? 0 : b.num_haps;
@@ -268,7 +275,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         read_max_all = std::max(read_max_all, read_max);
         pairs += static_cast<int64_t>(nr) * nh;
         // wave-groups: longest reads first, first-fit into 64 lanes
-        const int K = choose_rows_per_lane(read_max, nr, nh, static_cast<double>(hap_total) / nh, h->force_rows_per_lane);
+        const int K = choose_rows_per_lane(read_max, nr, nh, static_cast<double>(hap_total) / nh, call_pairs, h->force_rows_per_lane);
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
             return (b.read_offsets[x + 1] - b.read_offsets[x]) > (b.read_offsets[y + 1] - b.read_offsets[y]);
         });

@@ -1,0 +1,139 @@
+// C++ mirror of the reference's PairHMM plugin interface over the C-ABI (gatk_pairhmm.h).
+//
+// The reference's host side is Java (pairhmm/PairHMM.java); where no JDK is available this header
+// is the host-side stand-in with the same method names, argument meaning and error behaviour:
+//   initialize(readMaxLength, haplotypeMaxLength)            PairHMM.java:104
+//   computeLikelihoods(matrix, reads, gcp)                   PairHMM.java:190
+//   getLikelihoodArray()                                     PairHMM.java:360
+//   finalizeRegion() / close()                               PairHMM.java:124 / :364
+//   batchAdd(...) / batchGetResult()                         BatchPairHMM.java:33-40
+// Java exceptions become C++ exceptions of the same name.  Header-only; link libgatk_pairhmm_hip.so.
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "gatk_pairhmm.h"
+
+namespace gatk {
+
+struct IllegalArgumentException : std::invalid_argument { using std::invalid_argument::invalid_argument; };
+struct IllegalStateException : std::logic_error { using std::logic_error::logic_error; };
+struct ArrayIndexOutOfBoundsException : std::out_of_range { using std::out_of_range::out_of_range; };
+struct DeviceException : std::runtime_error { using std::runtime_error::runtime_error; };
+
+using Bytes = std::vector<uint8_t>;
+
+// What the PairHMM reads from a GATKSAMRecord (PairHMM.java:210-213).
+struct Read {
+    Bytes bases, quals, insertionQuals, deletionQuals;  // equal lengths
+};
+
+// ReadLikelihoods.Matrix (genotyper/ReadLikelihoods.java:652-756): values[allele][read].
+class LikelihoodMatrix {
+public:
+    LikelihoodMatrix(std::vector<Bytes> alleles, size_t readCount)
+        : alleles_(std::move(alleles)), reads_(readCount), values_(alleles_.size() * readCount, 0.0) {}
+    const std::vector<Bytes>& alleles() const { return alleles_; }
+    size_t alleleCount() const { return alleles_.size(); }
+    size_t readCount() const { return reads_; }
+    void set(size_t alleleIndex, size_t readIndex, double v) { values_[alleleIndex * reads_ + readIndex] = v; }
+    double get(size_t alleleIndex, size_t readIndex) const { return values_[alleleIndex * reads_ + readIndex]; }
+
+private:
+    std::vector<Bytes> alleles_;
+    size_t reads_;
+    std::vector<double> values_;
+};
+
+class HipLoglessPairHMM {
+public:
+    explicit HipLoglessPairHMM(int device = 0) { check(gatk_pairhmm_create(device, &h_)); }
+    ~HipLoglessPairHMM() { close(); }
+    HipLoglessPairHMM(const HipLoglessPairHMM&) = delete;
+    HipLoglessPairHMM& operator=(const HipLoglessPairHMM&) = delete;
+
+    void initialize(int readMaxLength, int haplotypeMaxLength) { check(gatk_pairhmm_initialize(h_, readMaxLength, haplotypeMaxLength)); }
+
+    // gcp: per-read gap-continuation penalties (the Map<GATKSAMRecord, byte[]> of the reference),
+    // indexed like `reads`.
+    void computeLikelihoods(LikelihoodMatrix& likelihoods, const std::vector<Read>& reads, const std::vector<Bytes>& gcp) {
+        if (reads.empty()) return;  // PairHMM.java:193
+        const auto& alleles = likelihoods.alleles();
+        Bytes rb, rq, ri, rd, rg, hb;
+        std::vector<int32_t> ro{0}, ho{0};
+        for (size_t r = 0; r < reads.size(); ++r) {
+            const Read& x = reads[r];
+            const size_t n = x.bases.size();
+            // PairHMM.java:276-279
+            if (x.quals.size() != n) throw IllegalArgumentException("Read bases and read quals aren't the same size");
+            if (x.insertionQuals.size() != n) throw IllegalArgumentException("Read bases and read insertion quals aren't the same size");
+            if (x.deletionQuals.size() != n) throw IllegalArgumentException("Read bases and read deletion quals aren't the same size");
+            if (gcp.at(r).size() != n) throw IllegalArgumentException("Read bases and overall GCP aren't the same size");
+            rb.insert(rb.end(), x.bases.begin(), x.bases.end());
+            rq.insert(rq.end(), x.quals.begin(), x.quals.end());
+            ri.insert(ri.end(), x.insertionQuals.begin(), x.insertionQuals.end());
+            rd.insert(rd.end(), x.deletionQuals.begin(), x.deletionQuals.end());
+            rg.insert(rg.end(), gcp[r].begin(), gcp[r].end());
+            ro.push_back(static_cast<int32_t>(rb.size()));
+        }
+        for (const Bytes& a : alleles) {
+            hb.insert(hb.end(), a.begin(), a.end());
+            ho.push_back(static_cast<int32_t>(hb.size()));
+        }
+        for (Bytes* v : {&rb, &rq, &ri, &rd, &rg, &hb}) v->push_back(0);
+        gatk_pairhmm_batch b{static_cast<int32_t>(reads.size()), static_cast<int32_t>(alleles.size()), rb.data(), rq.data(), ri.data(),
+                             rd.data(), rg.data(), ro.data(), hb.data(), ho.data()};
+        mLikelihoodArray_.assign(reads.size() * alleles.size(), 0.0);
+        check(gatk_pairhmm_compute_likelihoods(h_, &b, mLikelihoodArray_.data()));
+        size_t idx = 0;
+        for (size_t r = 0; r < reads.size(); ++r)
+            for (size_t a = 0; a < alleles.size(); ++a) likelihoods.set(a, r, mLikelihoodArray_[idx++]);  // PairHMM.java:224-225
+    }
+
+    const std::vector<double>& getLikelihoodArray() const { return mLikelihoodArray_; }
+
+    void batchAdd(const std::vector<Bytes>& haplotypes, const Bytes& readBases, const Bytes& readQuals, const Bytes& insertionGOP,
+                  const Bytes& deletionGOP, const Bytes& overallGCP) {
+        std::vector<const uint8_t*> hp;
+        std::vector<int32_t> hl;
+        for (const Bytes& h : haplotypes) { hp.push_back(h.data()); hl.push_back(static_cast<int32_t>(h.size())); }
+        check(gatk_pairhmm_batch_add(h_, static_cast<int32_t>(hp.size()), hp.data(), hl.data(), readBases.data(), readQuals.data(),
+                                     insertionGOP.data(), deletionGOP.data(), overallGCP.data(), static_cast<int32_t>(readBases.size())));
+    }
+
+    std::vector<double> batchGetResult() {
+        const double* p = nullptr;
+        int64_t n = 0;
+        check(gatk_pairhmm_batch_get_result(h_, &p, &n));
+        return std::vector<double>(p, p + n);
+    }
+
+    void finalizeRegion() { check(gatk_pairhmm_finalize_region(h_)); }
+
+    void close() {
+        if (h_) gatk_pairhmm_close(h_);
+        h_ = nullptr;
+    }
+
+    gatk_pairhmm* handle() const { return h_; }
+
+private:
+    static void check(int rc) {
+        if (rc == GATK_PAIRHMM_OK) return;
+        const std::string msg = gatk_pairhmm_last_error();
+        switch (rc) {
+            case GATK_PAIRHMM_ILLEGAL_ARGUMENT: throw IllegalArgumentException(msg);
+            case GATK_PAIRHMM_ILLEGAL_STATE: throw IllegalStateException(msg);
+            case GATK_PAIRHMM_INDEX_OUT_OF_BOUNDS: throw ArrayIndexOutOfBoundsException(msg);
+            default: throw DeviceException(msg);
+        }
+    }
+    gatk_pairhmm* h_ = nullptr;
+    std::vector<double> mLikelihoodArray_;
+};
+
+}  // namespace gatk

@@ -1,0 +1,107 @@
+// JNI veneer between org.broadinstitute.gatk.utils.pairhmm.HipLoglessPairHMM and the C-ABI of
+// libgatk_pairhmm_hip.so (include/gatk_pairhmm.h).  It only moves bytes: pins or copies the Java
+// arrays, calls one C entry point, maps the return code onto the exception the reference's own
+// PairHMM would have thrown.
+//
+// Built only where a JDK is present (jni.h); the image this repository is built in has none, so
+// the file compiles to nothing there.  Build on a JDK box with
+//   g++ -O2 -fPIC -shared -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
+//       java/jni/gatk_pairhmm_jni.cpp -Lgatk_amd -lgatk_pairhmm_hip -o libgatk_pairhmm_hip_jni.so
+#if __has_include(<jni.h>)
+#include <jni.h>
+
+#include <vector>
+
+#include "gatk_pairhmm.h"
+
+namespace {
+
+void throw_for(JNIEnv* env, int rc) {
+    const char* cls = "java/lang/RuntimeException";
+    switch (rc) {
+        case GATK_PAIRHMM_ILLEGAL_ARGUMENT: cls = "java/lang/IllegalArgumentException"; break;
+        case GATK_PAIRHMM_ILLEGAL_STATE: cls = "java/lang/IllegalStateException"; break;
+        case GATK_PAIRHMM_INDEX_OUT_OF_BOUNDS: cls = "java/lang/ArrayIndexOutOfBoundsException"; break;
+        case GATK_PAIRHMM_OUT_OF_MEMORY: cls = "java/lang/OutOfMemoryError"; break;
+        case GATK_PAIRHMM_DEVICE_ERROR: cls = "java/lang/IllegalStateException"; break;
+        default: break;
+    }
+    env->ThrowNew(env->FindClass(cls), gatk_pairhmm_last_error());
+}
+
+// Copies a byte[][] into one contiguous buffer with an offset table (the gatk_pairhmm_batch layout).
+bool flatten(JNIEnv* env, jobjectArray arrays, std::vector<uint8_t>& data, std::vector<int32_t>& offsets) {
+    const jsize n = env->GetArrayLength(arrays);
+    offsets.assign(1, 0);
+    for (jsize k = 0; k < n; ++k) {
+        jbyteArray a = static_cast<jbyteArray>(env->GetObjectArrayElement(arrays, k));
+        if (!a) return false;
+        const jsize len = env->GetArrayLength(a);
+        const size_t at = data.size();
+        data.resize(at + len);
+        env->GetByteArrayRegion(a, 0, len, reinterpret_cast<jbyte*>(data.data() + at));
+        env->DeleteLocalRef(a);
+        offsets.push_back(static_cast<int32_t>(data.size()));
+    }
+    data.push_back(0);  // never hand the C side a null data pointer
+    return true;
+}
+
+gatk_pairhmm* H(jlong h) { return reinterpret_cast<gatk_pairhmm*>(h); }
+
+}  // namespace
+
+extern "C" {
+
+JNIEXPORT jlong JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniCreate(JNIEnv* env, jclass, jint device) {
+    gatk_pairhmm* h = nullptr;
+    if (const int rc = gatk_pairhmm_create(device, &h)) { throw_for(env, rc); return 0; }
+    return reinterpret_cast<jlong>(h);
+}
+
+JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniInitialize(JNIEnv* env, jclass, jlong h, jint readMax, jint hapMax) {
+    if (const int rc = gatk_pairhmm_initialize(H(h), readMax, hapMax)) throw_for(env, rc);
+}
+
+JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniComputeLikelihoods(
+    JNIEnv* env, jclass, jlong h, jobjectArray readBases, jobjectArray readQuals, jobjectArray insGOP, jobjectArray delGOP,
+    jobjectArray gcp, jobjectArray hapBases, jdoubleArray likelihoodArray) {
+    std::vector<uint8_t> rb, rq, ri, rd, rg, hb;
+    std::vector<int32_t> ro, o2, ho;
+    if (!flatten(env, readBases, rb, ro) || !flatten(env, readQuals, rq, o2) || !flatten(env, insGOP, ri, o2) ||
+        !flatten(env, delGOP, rd, o2) || !flatten(env, gcp, rg, o2) || !flatten(env, hapBases, hb, ho)) {
+        env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "readBases cannot be null");
+        return;
+    }
+    gatk_pairhmm_batch b{static_cast<int32_t>(ro.size()) - 1, static_cast<int32_t>(ho.size()) - 1, rb.data(), rq.data(), ri.data(),
+                         rd.data(), rg.data(), ro.data(), hb.data(), ho.data()};
+    std::vector<double> out(static_cast<size_t>(b.num_reads) * b.num_haps);
+    if (const int rc = gatk_pairhmm_compute_likelihoods(H(h), &b, out.data())) { throw_for(env, rc); return; }
+    env->SetDoubleArrayRegion(likelihoodArray, 0, static_cast<jsize>(out.size()), out.data());
+}
+
+JNIEXPORT jdouble JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniComputePair(
+    JNIEnv* env, jclass, jlong h, jbyteArray hap, jbyteArray bases, jbyteArray quals, jbyteArray ins, jbyteArray del, jbyteArray gcp) {
+    auto get = [&](jbyteArray a) {
+        std::vector<uint8_t> v(static_cast<size_t>(env->GetArrayLength(a)) + 1);
+        env->GetByteArrayRegion(a, 0, static_cast<jsize>(v.size()) - 1, reinterpret_cast<jbyte*>(v.data()));
+        return v;
+    };
+    const auto vh = get(hap), vb = get(bases), vq = get(quals), vi = get(ins), vd = get(del), vg = get(gcp);
+    double lk = 0;
+    const int rc = gatk_pairhmm_compute_pair(H(h), vh.data(), static_cast<int32_t>(vh.size()) - 1, vb.data(), vq.data(), vi.data(),
+                                             vd.data(), vg.data(), static_cast<int32_t>(vb.size()) - 1, &lk);
+    if (rc) throw_for(env, rc);
+    return lk;
+}
+
+JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniFinalizeRegion(JNIEnv* env, jclass, jlong h) {
+    if (const int rc = gatk_pairhmm_finalize_region(H(h))) throw_for(env, rc);
+}
+
+JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniClose(JNIEnv*, jclass, jlong h) {
+    gatk_pairhmm_close(H(h));
+}
+
+}  // extern "C"
+#endif  // __has_include(<jni.h>)

@@ -316,3 +316,11 @@ def subset_reads(b, idx):
     offs = np.zeros(len(idx) + 1, np.int32)
     offs[1:] = np.cumsum([p.stop - p.start for p in parts])
     return Batch(cat(b.read_bases), cat(b.read_quals), cat(b.ins_gop), cat(b.del_gop), cat(b.gcp), offs, b.hap_bases, b.hap_offsets)
+
+
+def test_cxx_host_mirror():
+    """include/gatk_pairhmm.hpp (the C++ stand-in for the Java PairHMM subclass) against closed-form answers."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gatk_amd", "cxx_driver")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "cxx_driver ok" in r.stdout, r.stdout + r.stderr

@@ -68,6 +68,26 @@ def main():
                 rc, ref = O.compute_likelihoods(b, O.LOGLESS, fast_threads=8)
                 print("   C3 slice parity max|d| =", np.abs(out - ref).max(), flush=True)
             res.free()
+    # host-pointer path on the large batch: planning + H2D + kernels + D2H
+    hmm.set_option("force_rows_per_lane", 0)
+    hmm.set_option("emit_mode", -1)
+    b = synth.config_c3()
+    hmm.compute_batch(b)
+    t0 = time.time()
+    for _ in range(5):
+        hmm.compute_batch(b)
+    dt = (time.time() - t0) / 5
+    print(f"C3 host-pointer path (plan + H2D + kernels + D2H): {dt * 1e3:.2f} ms/call -> {b.cells / dt / 1e9:.1f} GCUPS", flush=True)
+    regions = synth.make_regions(2000, seed=5)
+    cells = sum(r.cells for r in regions)
+    hmm.compute_regions(regions[:10])
+    t0 = time.time()
+    outs = hmm.compute_regions(regions)
+    dt = time.time() - t0
+    st = hmm.stats()
+    print(f"2000 HC-shaped regions in one pass: cells={cells:.3e} pairs={st['pairs']} wall={dt * 1e3:.1f} ms -> {cells / dt / 1e9:.1f} GCUPS; "
+          f"kernels fp32={st['fp32_kernel_ms']:.2f} ms fp64={st['fp64_kernel_ms']:.2f} ms -> {cells / (st['fp32_kernel_ms'] + st['fp64_kernel_ms']) / 1e6:.1f} GCUPS; "
+          f"tasks={st['wave_tasks']} rerun={st['rerun_tasks']}", flush=True)
     hmm.close()
     print("gpu_check done")
 
