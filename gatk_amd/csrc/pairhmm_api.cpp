@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -69,12 +70,36 @@ struct DevBuf {
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
+// Grow-only pinned host buffer (staging for the one H2D and the one D2H copy of a call).
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipHostFree(p);
+            p = nullptr; cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        size_t want = bytes + bytes / 2 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+    }
+};
+
 struct Bucket {
     int rows_per_lane = 0;
-    int task_begin = 0;  // offset into the task array
+    int task_begin = 0;   // offset of this bucket in the rerun-list array
     int num_tasks = 0;
+    int desc_begin = 0;   // first RegionDesc of this bucket
+    int num_descs = 0;
     int max_hap_len = 0;
-    int emit_mode = kEmitCompare;     // fp32 pass
+    int emit_mode = kEmitCompare;       // fp32 pass
     int emit_mode_fp64 = kEmitCompare;  // fp64 pass: always compares bytes
 };
 
@@ -84,24 +109,22 @@ struct gatk_pairhmm_resident {
     // ---- host-side plan ----
     int num_regions = 0;
     std::vector<int64_t> region_out_off;  // [num_regions + 1] offsets into the concatenated output
-    int64_t total_pairs = 0, cells = 0;
+    int64_t total_pairs = 0, cells = 0, total_tasks = 0;
     int64_t total_read_bytes = 0;
-    int num_reads = 0, num_haps = 0, num_groups = 0;
     std::vector<Bucket> buckets;
-    std::vector<Task> tasks;
-    std::vector<int32_t> group_segs;   // reads packed in each group
-    std::vector<int32_t> neg_inf_idx;  // output slots of zero-length reads
+    std::vector<RegionDesc> descs;      // as uploaded, bucket by bucket
+    std::vector<uint8_t> group_segs;    // reads packed in each wave-group
+    int32_t num_neg_inf = 0;            // output slots of zero-length reads
     bool computed = false;
+    double plan_ms = 0, upload_ms = 0;
     // ---- device ----
-    DevBuf d_read_bases, d_read_quals, d_ins, d_del, d_gcp, d_read_off, d_read_out_base;
-    DevBuf d_hap_pool, d_hap_off, d_hap_len, d_hap_local, d_lanes, d_group_fill, d_tasks;
-    DevBuf d_out, d_rerun_lists, d_counters, d_neg_inf_idx;
+    DevBuf d_arena;  // every input array of the call, one H2D copy
+    DevBuf d_out, d_rerun_lists, d_counters;
+    DeviceBatch base{};  // pointers into d_arena
+    const int32_t* d_neg_inf_idx = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     void release() {
-        for (DevBuf* b : {&d_read_bases, &d_read_quals, &d_ins, &d_del, &d_gcp, &d_read_off, &d_read_out_base, &d_hap_pool,
-                          &d_hap_off, &d_hap_len, &d_hap_local, &d_lanes, &d_group_fill, &d_tasks, &d_out, &d_rerun_lists,
-                          &d_counters, &d_neg_inf_idx})
-            b->release();
+        for (DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_counters}) b->release();
         for (auto& e : ev)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
     }
@@ -120,6 +143,7 @@ struct gatk_pairhmm {
     bool force_fp64 = false;
     bool timing = false;
     gatk_pairhmm_resident scratch;  // buffers reused by the host-pointer entry points
+    PinnedBuf stage_in, stage_out;  // pinned staging shared by every upload / download on this handle
     std::vector<double> likelihood_array;
     gatk_pairhmm_stats stats{};
     // BatchPairHMM queue: one single-read region per batchAdd
@@ -132,6 +156,10 @@ struct gatk_pairhmm {
 };
 
 namespace {
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // ---------------------------------------------------------------------------------------------
 // Planner
@@ -191,146 +219,171 @@ int check_region(const gatk_pairhmm_batch& b, int k) {
     if (read_max > kWave * kMaxRowsPerLane - 1)
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "readBases is too long, got " + std::to_string(read_max) + " but max is " +
                                                        std::to_string(kWave * kMaxRowsPerLane - 1) + where);
+    if (hap_max > kMaxHapLen)
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "Haplotype bases is too long, got " + std::to_string(hap_max) + " but max is " +
+                                                       std::to_string(kMaxHapLen) + where);
     return GATK_PAIRHMM_OK;
 }
 
-template <typename T>
-int upload_vec(DevBuf& buf, const std::vector<T>& v, hipStream_t s) {
-    HIP_TRY(buf.ensure(std::max<size_t>(v.size() * sizeof(T), 16)));
-    if (!v.empty()) HIP_TRY(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
-    return GATK_PAIRHMM_OK;
-}
+// Carves aligned sub-arrays out of one staging buffer; the same offsets are valid in the device arena.
+struct ArenaLayout {
+    size_t size = 0;
+    size_t add(size_t bytes) {
+        const size_t at = size;
+        size = (size + bytes + 255) & ~size_t{255};
+        return at;
+    }
+};
+
+// Per-region planning record (host only).
+struct RegionPlan {
+    int region = 0, K = 0, nr = 0, nh = 0;
+    int read_begin = 0;   // global index of the region's first read
+    int hap_begin = 0;    // global index of its first haplotype
+    int group_begin = 0, num_groups = 0;
+    int hap_max = 0, cost = 0;
+};
 
 int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, const gatk_pairhmm_batch* regions) {
+    const double t_begin = now_ms();
     if (num_regions < 0 || (num_regions > 0 && !regions)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "regions cannot be null");
     for (int k = 0; k < num_regions; ++k)
         if (int rc = check_region(regions[k], k)) return rc;
 
     R->num_regions = num_regions;
     R->region_out_off.assign(num_regions + 1, 0);
-    R->buckets.clear(); R->tasks.clear(); R->group_segs.clear(); R->neg_inf_idx.clear();
+    R->buckets.clear(); R->descs.clear(); R->group_segs.clear();
     R->computed = false;
 
-    std::vector<uint8_t> rb, rq, ri, rd, rg, hap_pool;
-    std::vector<int32_t> read_off{0}, read_out_base, hap_off, hap_len, hap_local, group_fill;
-    std::vector<LaneDesc> lanes;
-    std::vector<std::vector<Task>> tasks_by_k(kMaxRowsPerLane + 1);
-    std::vector<int> hap_max_by_k(kMaxRowsPerLane + 1, 0);
-    bool any_hap_n = false, any_hap_other = false;
-    int64_t cells = 0, pairs = 0;
-    int read_max_all = 0, hap_max_all = 0;
-
-    int64_t call_pairs = 0;
-    for (int k = 0; k < num_regions; ++k) call_pairs += static_cast<int64_t>(regions[k].num_reads) * regions[k].num_haps;
-
+    // ---- pass 1: sizes, rows per lane, wave-groups ------------------------------------------------
+    int64_t call_pairs = 0, total_reads = 0, total_haps = 0, total_read_bytes = 0, hap_pool_bytes = 0;
     for (int k = 0; k < num_regions; ++k) {
         const gatk_pairhmm_batch& b = regions[k];
-        const int nr = b.num_reads, nh = b.num_reads == 0 ? 0 : b.num_haps;
+        const int nr = b.num_reads, nh = nr == 0 ? 0 : b.num_haps;
         R->region_out_off[k + 1] = R->region_out_off[k] + static_cast<int64_t>(nr) * nh;
         if (nr == 0 || nh == 0) continue;
-        if (R->region_out_off[k + 1] >= (int64_t{1} << 31)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "more than 2^31 pairs in one call");
-        // haplotypes
-        const int hap_base_idx = static_cast<int>(hap_len.size());
+        call_pairs += static_cast<int64_t>(nr) * nh;
+        total_reads += nr;
+        total_haps += nh;
+        total_read_bytes += b.read_offsets[nr] - b.read_offsets[0];
+        for (int a = 0; a < nh; ++a) hap_pool_bytes += (b.hap_offsets[a + 1] - b.hap_offsets[a] + 15) & ~15;
+    }
+    if (call_pairs >= (int64_t{1} << 31) || total_read_bytes >= (int64_t{1} << 31) || hap_pool_bytes >= (int64_t{1} << 31))
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "more than 2^31 pairs or bytes in one call");
+
+    std::vector<RegionPlan> plans;
+    plans.reserve(num_regions);
+    std::vector<GroupDesc> groups;
+    std::vector<SegDesc> segs;
+    segs.reserve(static_cast<size_t>(total_reads));
+    std::vector<int32_t> neg_inf_idx;
+    std::vector<int> order;
+    bool any_hap_n = false, any_hap_other = false;
+    int64_t cells = 0;
+    int read_max_all = 0, hap_max_all = 0;
+    int read_cursor = 0, hap_cursor = 0;
+    for (int k = 0; k < num_regions; ++k) {
+        const gatk_pairhmm_batch& b = regions[k];
+        const int nr = b.num_reads, nh = nr == 0 ? 0 : b.num_haps;
+        if (nr == 0 || nh == 0) continue;
+        RegionPlan rp;
+        rp.region = k; rp.nr = nr; rp.nh = nh;
+        rp.read_begin = read_cursor; rp.hap_begin = hap_cursor;
         int64_t hap_total = 0;
-        int hap_max = 0;
         for (int a = 0; a < nh; ++a) {
             const int o = b.hap_offsets[a], len = b.hap_offsets[a + 1] - o;
-            hap_off.push_back(static_cast<int32_t>(hap_pool.size()));
-            hap_len.push_back(len);
-            hap_local.push_back(a);
-            hap_pool.insert(hap_pool.end(), b.hap_bases + o, b.hap_bases + o + len);
-            hap_pool.resize((hap_pool.size() + 15) & ~size_t{15}, 0);
-            for (int x = 0; x < len; ++x) {
-                const uint8_t c = b.hap_bases[o + x];
-                if (c == 'N') any_hap_n = true;
-                else if (c != 'A' && c != 'C' && c != 'G' && c != 'T') any_hap_other = true;
-            }
             hap_total += len;
-            hap_max = std::max(hap_max, len);
+            rp.hap_max = std::max(rp.hap_max, len);
+            if (!any_hap_other)
+                for (int x = 0; x < len; ++x) {
+                    const uint8_t c = b.hap_bases[o + x];
+                    if (c == 'N') any_hap_n = true;
+                    else if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { any_hap_other = true; break; }
+                }
         }
-        hap_max_all = std::max(hap_max_all, hap_max);
-        // reads
-        const int read_base_idx = static_cast<int>(read_out_base.size());
-        const int bo = b.read_offsets[0];
-        const int total = b.read_offsets[nr] - bo;
-        const int32_t byte_base = read_off.back();
-        rb.insert(rb.end(), b.read_bases + bo, b.read_bases + bo + total);
-        rq.insert(rq.end(), b.read_quals + bo, b.read_quals + bo + total);
-        ri.insert(ri.end(), b.ins_gop + bo, b.ins_gop + bo + total);
-        rd.insert(rd.end(), b.del_gop + bo, b.del_gop + bo + total);
-        rg.insert(rg.end(), b.gcp + bo, b.gcp + bo + total);
-        std::vector<int> order;
-        order.reserve(nr);
+        hap_max_all = std::max(hap_max_all, rp.hap_max);
+        order.clear();
         int read_max = 0;
         for (int r = 0; r < nr; ++r) {
             const int len = b.read_offsets[r + 1] - b.read_offsets[r];
-            read_off.push_back(byte_base + (b.read_offsets[r + 1] - bo));
-            read_out_base.push_back(static_cast<int32_t>(R->region_out_off[k] + static_cast<int64_t>(r) * nh));
             read_max = std::max(read_max, len);
             cells += static_cast<int64_t>(len) * hap_total;
             if (len > 0) order.push_back(r);
             else  // a zero-length read sums an empty last row: log10(0) (Log10PairHMM.java:128-134 on row 0)
-                for (int a = 0; a < nh; ++a) R->neg_inf_idx.push_back(read_out_base.back() + a);
+                for (int a = 0; a < nh; ++a)
+                    neg_inf_idx.push_back(static_cast<int32_t>(R->region_out_off[k] + static_cast<int64_t>(r) * nh + a));
         }
         read_max_all = std::max(read_max_all, read_max);
-        pairs += static_cast<int64_t>(nr) * nh;
-        // wave-groups: longest reads first, first-fit into 64 lanes
         const int K = choose_rows_per_lane(read_max, nr, nh, static_cast<double>(hap_total) / nh, call_pairs, h->force_rows_per_lane);
+        rp.K = K;
+        // wave-groups: longest reads first, filled lane segment by lane segment up to 64 lanes
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
             return (b.read_offsets[x + 1] - b.read_offsets[x]) > (b.read_offsets[y + 1] - b.read_offsets[y]);
         });
-        const int first_group = static_cast<int>(group_fill.size());
+        rp.group_begin = static_cast<int>(groups.size());
         size_t pos = 0;
+        int max_fill = 0;
         while (pos < order.size()) {
-            const size_t lane_base = lanes.size();
-            lanes.resize(lane_base + kWave, LaneDesc{-1, 1, 0, 0});
-            int used = 0, max_seg = 0, segs = 0;
+            GroupDesc g{static_cast<int32_t>(segs.size()), 0, 0};
+            int used = 0, max_seg = 0;
             while (pos < order.size()) {
                 const int r = order[pos];
                 const int len = b.read_offsets[r + 1] - b.read_offsets[r];
                 const int seg = (len + K) / K;  // rows >= len + 1: every segment starts with a pad row
                 if (used + seg > kWave) break;
-                const int pad_top = seg * K - len;
-                for (int t = 0; t < seg; ++t) {
-                    LaneDesc& ld = lanes[lane_base + used + t];
-                    ld.read_idx = read_base_idx + r;
-                    ld.first_row = t * K + 1 - pad_top;
-                    ld.seg_lane = t;
-                    ld.seg_last = (t == seg - 1) ? 1 : 0;
-                }
+                segs.push_back(SegDesc{rp.read_begin + r, static_cast<uint8_t>(used), static_cast<uint8_t>(seg), 0});
                 used += seg;
                 max_seg = std::max(max_seg, seg);
-                ++segs; ++pos;
+                ++g.num_segs; ++pos;
             }
-            group_fill.push_back(max_seg - 1);
-            R->group_segs.push_back(segs);
+            g.fill = static_cast<int16_t>(max_seg - 1);
+            max_fill = std::max(max_fill, max_seg - 1);
+            groups.push_back(g);
+            R->group_segs.push_back(static_cast<uint8_t>(g.num_segs));
         }
-        const int last_group = static_cast<int>(group_fill.size());
-        for (int a = 0; a < nh; ++a)
-            for (int g = first_group; g < last_group; ++g) tasks_by_k[K].push_back(Task{g, hap_base_idx + a});
-        hap_max_by_k[K] = std::max(hap_max_by_k[K], hap_max);
+        rp.num_groups = static_cast<int>(groups.size()) - rp.group_begin;
+        rp.cost = rp.hap_max + max_fill;
+        read_cursor += nr;
+        hap_cursor += nh;
+        if (rp.num_groups > 0) plans.push_back(rp);
     }
-    if (hap_max_all > 16000) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "Haplotype bases is too long, got " + std::to_string(hap_max_all) + " but max is 16000");
 
     // PairHMM.java:200-201: grow the instance's maxima when a batch exceeds them
-    if (pairs > 0 && (!h->initialized || read_max_all > h->max_read || hap_max_all > h->max_hap)) {
+    if (call_pairs > 0 && (!h->initialized || read_max_all > h->max_read || hap_max_all > h->max_hap)) {
         h->max_read = std::max(h->max_read, read_max_all);
         h->max_hap = std::max(h->max_hap, hap_max_all);
         h->initialized = true;
     }
 
-    // longest tasks first inside each bucket, so the tail of a launch is made of short tasks
-    for (int K = 1; K <= kMaxRowsPerLane; ++K) {
-        auto& tv = tasks_by_k[K];
-        if (tv.empty()) continue;
-        std::stable_sort(tv.begin(), tv.end(), [&](const Task& x, const Task& y) {
-            return hap_len[x.hap] + group_fill[x.group] > hap_len[y.hap] + group_fill[y.group];
-        });
+    // ---- buckets: one launch per rows-per-lane value; longest work items first -----------------
+    std::vector<int> by_cost(plans.size());
+    std::iota(by_cost.begin(), by_cost.end(), 0);
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int x, int y) {
+        return plans[x].K != plans[y].K ? plans[x].K < plans[y].K : plans[x].cost > plans[y].cost;
+    });
+    int64_t total_tasks = 0;
+    for (size_t i = 0; i < by_cost.size();) {
+        const int K = plans[by_cost[i]].K;
         Bucket bk;
         bk.rows_per_lane = K;
-        bk.task_begin = static_cast<int>(R->tasks.size());
-        bk.num_tasks = static_cast<int>(tv.size());
-        bk.max_hap_len = hap_max_by_k[K];
+        bk.task_begin = static_cast<int>(total_tasks);
+        bk.desc_begin = static_cast<int>(R->descs.size());
+        int64_t t = 0;
+        for (; i < by_cost.size() && plans[by_cost[i]].K == K; ++i) {
+            const RegionPlan& rp = plans[by_cost[i]];
+            RegionDesc d{};
+            d.task_begin = static_cast<int32_t>(t);
+            d.group_begin = rp.group_begin;
+            d.num_groups = rp.num_groups;
+            d.hap_begin = rp.hap_begin;
+            d.num_haps = rp.nh;
+            R->descs.push_back(d);
+            t += static_cast<int64_t>(rp.num_groups) * rp.nh;
+            bk.max_hap_len = std::max(bk.max_hap_len, rp.hap_max);
+        }
+        if (total_tasks + t >= (int64_t{1} << 31)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "more than 2^31 work items in one call");
+        bk.num_tasks = static_cast<int>(t);
+        bk.num_descs = static_cast<int>(R->descs.size()) - bk.desc_begin;
         bk.emit_mode_fp64 = any_hap_n ? kEmitCompareN : kEmitCompare;
         bk.emit_mode = bk.emit_mode_fp64;
         if (!any_hap_other && h->emit_mode != 0) {
@@ -338,44 +391,102 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             // the table must leave room for at least one workgroup per CU (64 KiB dynamic LDS per block)
             if (lds_bytes_per_wave(K, lut, bk.max_hap_len) * kWavesPerBlock <= 64 * 1024) bk.emit_mode = lut;
         }
-        R->tasks.insert(R->tasks.end(), tv.begin(), tv.end());
+        total_tasks += t;
         R->buckets.push_back(bk);
     }
-    R->total_pairs = pairs;
+    R->total_pairs = call_pairs;
     R->cells = cells;
-    R->total_read_bytes = static_cast<int64_t>(rb.size());
-    R->num_reads = static_cast<int>(read_out_base.size());
-    R->num_haps = static_cast<int>(hap_len.size());
-    R->num_groups = static_cast<int>(group_fill.size());
+    R->total_tasks = total_tasks;
+    R->total_read_bytes = total_read_bytes;
+    R->num_neg_inf = static_cast<int32_t>(neg_inf_idx.size());
+
+    // ---- pass 2: lay the call out in the pinned staging buffer, one H2D copy ---------------------
+    ArenaLayout L;
+    const size_t rbytes = static_cast<size_t>(total_read_bytes);
+    const size_t o_rb = L.add(rbytes + 16), o_rq = L.add(rbytes + 16), o_ri = L.add(rbytes + 16), o_rd = L.add(rbytes + 16),
+                 o_rg = L.add(rbytes + 16);
+    const size_t o_roff = L.add((total_reads + 1) * sizeof(int32_t));
+    const size_t o_rout = L.add((total_reads + 1) * sizeof(int32_t));
+    const size_t o_hpool = L.add(static_cast<size_t>(hap_pool_bytes) + 32);
+    const size_t o_hoff = L.add((total_haps + 1) * sizeof(int32_t));
+    const size_t o_hlen = L.add((total_haps + 1) * sizeof(int32_t));
+    const size_t o_groups = L.add((groups.size() + 1) * sizeof(GroupDesc));
+    const size_t o_segs = L.add((segs.size() + 1) * sizeof(SegDesc));
+    const size_t o_descs = L.add((R->descs.size() + 1) * sizeof(RegionDesc));
+    const size_t o_neg = L.add((neg_inf_idx.size() + 1) * sizeof(int32_t));
 
     HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(h->stage_in.ensure(L.size));
+    uint8_t* S = static_cast<uint8_t*>(h->stage_in.p);
+    int32_t* roff = reinterpret_cast<int32_t*>(S + o_roff);
+    int32_t* rout = reinterpret_cast<int32_t*>(S + o_rout);
+    int32_t* hoff = reinterpret_cast<int32_t*>(S + o_hoff);
+    int32_t* hlen = reinterpret_cast<int32_t*>(S + o_hlen);
+    size_t rcur = 0, hcur = 0;
+    int ri = 0, hi = 0;
+    roff[0] = 0;
+    for (int k = 0; k < num_regions; ++k) {
+        const gatk_pairhmm_batch& b = regions[k];
+        const int nr = b.num_reads, nh = nr == 0 ? 0 : b.num_haps;
+        if (nr == 0 || nh == 0) continue;
+        const int bo = b.read_offsets[0];
+        const size_t total = static_cast<size_t>(b.read_offsets[nr] - bo);
+        memcpy(S + o_rb + rcur, b.read_bases + bo, total);
+        memcpy(S + o_rq + rcur, b.read_quals + bo, total);
+        memcpy(S + o_ri + rcur, b.ins_gop + bo, total);
+        memcpy(S + o_rd + rcur, b.del_gop + bo, total);
+        memcpy(S + o_rg + rcur, b.gcp + bo, total);
+        for (int r = 0; r < nr; ++r) {
+            rout[ri] = static_cast<int32_t>(R->region_out_off[k] + static_cast<int64_t>(r) * nh);
+            roff[++ri] = static_cast<int32_t>(rcur + (b.read_offsets[r + 1] - bo));
+        }
+        rcur += total;
+        for (int a = 0; a < nh; ++a) {
+            const int o = b.hap_offsets[a], len = b.hap_offsets[a + 1] - o;
+            hoff[hi] = static_cast<int32_t>(hcur);
+            hlen[hi++] = len;
+            memcpy(S + o_hpool + hcur, b.hap_bases + o, len);
+            const size_t padded = (static_cast<size_t>(len) + 15) & ~size_t{15};
+            memset(S + o_hpool + hcur + len, 0, padded - len);
+            hcur += padded;
+        }
+    }
+    memset(S + o_hpool + hcur, 0, 32);
+    if (!groups.empty()) memcpy(S + o_groups, groups.data(), groups.size() * sizeof(GroupDesc));
+    if (!segs.empty()) memcpy(S + o_segs, segs.data(), segs.size() * sizeof(SegDesc));
+    if (!R->descs.empty()) memcpy(S + o_descs, R->descs.data(), R->descs.size() * sizeof(RegionDesc));
+    if (!neg_inf_idx.empty()) memcpy(S + o_neg, neg_inf_idx.data(), neg_inf_idx.size() * sizeof(int32_t));
+    const double t_planned = now_ms();
+
     hipStream_t s = h->stream;
-    hap_pool.resize(hap_pool.size() + 16, 0);
-    if (int rc = upload_vec(R->d_read_bases, rb, s)) return rc;
-    if (int rc = upload_vec(R->d_read_quals, rq, s)) return rc;
-    if (int rc = upload_vec(R->d_ins, ri, s)) return rc;
-    if (int rc = upload_vec(R->d_del, rd, s)) return rc;
-    if (int rc = upload_vec(R->d_gcp, rg, s)) return rc;
-    if (int rc = upload_vec(R->d_read_off, read_off, s)) return rc;
-    if (int rc = upload_vec(R->d_read_out_base, read_out_base, s)) return rc;
-    if (int rc = upload_vec(R->d_hap_pool, hap_pool, s)) return rc;
-    if (int rc = upload_vec(R->d_hap_off, hap_off, s)) return rc;
-    if (int rc = upload_vec(R->d_hap_len, hap_len, s)) return rc;
-    if (int rc = upload_vec(R->d_hap_local, hap_local, s)) return rc;
-    if (int rc = upload_vec(R->d_lanes, lanes, s)) return rc;
-    if (int rc = upload_vec(R->d_group_fill, group_fill, s)) return rc;
-    if (int rc = upload_vec(R->d_tasks, R->tasks, s)) return rc;
-    if (int rc = upload_vec(R->d_neg_inf_idx, R->neg_inf_idx, s)) return rc;
-    HIP_TRY(R->d_out.ensure(std::max<size_t>(static_cast<size_t>(pairs) * sizeof(double), 16)));
-    HIP_TRY(R->d_rerun_lists.ensure(std::max<size_t>(R->tasks.size() * sizeof(int32_t), 16)));
+    HIP_TRY(R->d_arena.ensure(L.size));
+    HIP_TRY(R->d_out.ensure(std::max<size_t>(static_cast<size_t>(call_pairs) * sizeof(double), 16)));
+    HIP_TRY(R->d_rerun_lists.ensure(std::max<size_t>(static_cast<size_t>(total_tasks) * sizeof(int32_t), 16)));
     HIP_TRY(R->d_counters.ensure(256));
-    // the host vectors above are pageable and die with this scope: finish the copies first
+    if (L.size) HIP_TRY(hipMemcpyAsync(R->d_arena.p, S, L.size, hipMemcpyHostToDevice, s));
+    const uint8_t* D = R->d_arena.as<uint8_t>();
+    DeviceBatch& B = R->base;
+    B = DeviceBatch{};
+    B.read_bases = D + o_rb; B.read_quals = D + o_rq; B.ins_gop = D + o_ri; B.del_gop = D + o_rd; B.gcp = D + o_rg;
+    B.read_off = reinterpret_cast<const int32_t*>(D + o_roff);
+    B.read_out_base = reinterpret_cast<const int32_t*>(D + o_rout);
+    B.hap_pool = D + o_hpool;
+    B.hap_off = reinterpret_cast<const int32_t*>(D + o_hoff);
+    B.hap_len = reinterpret_cast<const int32_t*>(D + o_hlen);
+    B.groups = reinterpret_cast<const GroupDesc*>(D + o_groups);
+    B.segs = reinterpret_cast<const SegDesc*>(D + o_segs);
+    B.region_descs = reinterpret_cast<const RegionDesc*>(D + o_descs);
+    B.total_read_bytes = total_read_bytes;
+    R->d_neg_inf_idx = reinterpret_cast<const int32_t*>(D + o_neg);
+    // the staging buffer is reused by the next upload on this handle: finish the copy first
     HIP_TRY(hipStreamSynchronize(s));
+    R->plan_ms = t_planned - t_begin;
+    R->upload_ms = now_ms() - t_planned;
     return GATK_PAIRHMM_OK;
 }
 
 // counters layout: [0] error word, [1 + b] rerun count of bucket b
-constexpr int kMaxBuckets = kMaxRowsPerLane;  // one bucket per rows-per-lane value in use
+constexpr int kMaxBuckets = 16;  // one bucket per rows-per-lane value in use
 
 int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     HIP_TRY(hipSetDevice(h->device));
@@ -385,59 +496,54 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
         for (auto& e : R->ev)
             if (!e) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipMemsetAsync(R->d_counters.p, 0, 256, s));
-    DeviceBatch B{};
-    B.read_bases = R->d_read_bases.as<uint8_t>();
-    B.read_quals = R->d_read_quals.as<uint8_t>();
-    B.ins_gop = R->d_ins.as<uint8_t>();
-    B.del_gop = R->d_del.as<uint8_t>();
-    B.gcp = R->d_gcp.as<uint8_t>();
-    B.read_off = R->d_read_off.as<int32_t>();
-    B.read_out_base = R->d_read_out_base.as<int32_t>();
-    B.hap_pool = R->d_hap_pool.as<uint8_t>();
-    B.hap_off = R->d_hap_off.as<int32_t>();
-    B.hap_len = R->d_hap_len.as<int32_t>();
-    B.hap_local = R->d_hap_local.as<int32_t>();
-    B.lanes = R->d_lanes.as<LaneDesc>();
-    B.group_fill = R->d_group_fill.as<int32_t>();
+    DeviceBatch B = R->base;
     B.err_prob = h->d_err;
     B.match_to_match = h->d_mm;
     B.out = R->d_out.as<double>();
     B.error_word = R->d_counters.as<int32_t>();
     B.fp32_threshold = h->fp32_threshold;
-    B.total_read_bytes = R->total_read_bytes;
     HIP_TRY(launch_validate(B, s));
-    if (!R->neg_inf_idx.empty())
-        HIP_TRY(launch_fill_neg_inf(B.out, R->d_neg_inf_idx.as<int32_t>(), static_cast<int>(R->neg_inf_idx.size()), s));
+    if (R->num_neg_inf > 0) HIP_TRY(launch_fill_neg_inf(B.out, R->d_neg_inf_idx, R->num_neg_inf, s));
     if (timing) HIP_TRY(hipEventRecord(R->ev[0], s));
-    for (size_t bi = 0; bi < R->buckets.size(); ++bi) {
+    auto bucket_args = [&](size_t bi, int mode) {
         const Bucket& bk = R->buckets[bi];
         DeviceBatch L = B;
-        L.tasks = R->d_tasks.as<Task>() + bk.task_begin;
+        L.region_descs = B.region_descs + bk.desc_begin;
+        L.num_region_descs = bk.num_descs;
         L.num_tasks = bk.num_tasks;
         L.rerun_count = R->d_counters.as<int32_t>() + 1 + bi;
         L.rerun_list = R->d_rerun_lists.as<int32_t>() + bk.task_begin;
-        const int mode = h->force_fp64 ? bk.emit_mode_fp64 : bk.emit_mode;
         L.lds_per_wave = lds_bytes_per_wave(bk.rows_per_lane, mode, bk.max_hap_len);
+        return L;
+    };
+    for (size_t bi = 0; bi < R->buckets.size(); ++bi) {
+        const Bucket& bk = R->buckets[bi];
+        const int mode = h->force_fp64 ? bk.emit_mode_fp64 : bk.emit_mode;
         const int blocks = (bk.num_tasks + kWavesPerBlock - 1) / kWavesPerBlock;
-        HIP_TRY(launch_forward(L, bk.rows_per_lane, mode, h->force_fp64, false, blocks, s));
+        HIP_TRY(launch_forward(bucket_args(bi, mode), bk.rows_per_lane, mode, h->force_fp64, false, blocks, s));
     }
     if (timing) HIP_TRY(hipEventRecord(R->ev[1], s));
     if (!h->force_fp64) {
         for (size_t bi = 0; bi < R->buckets.size(); ++bi) {
             const Bucket& bk = R->buckets[bi];
-            DeviceBatch L = B;
-            L.tasks = R->d_tasks.as<Task>() + bk.task_begin;
-            L.num_tasks = bk.num_tasks;
-            L.rerun_count = R->d_counters.as<int32_t>() + 1 + bi;
-            L.rerun_list = R->d_rerun_lists.as<int32_t>() + bk.task_begin;
-            L.lds_per_wave = lds_bytes_per_wave(bk.rows_per_lane, bk.emit_mode_fp64, bk.max_hap_len);
             const int blocks = std::min((bk.num_tasks + kWavesPerBlock - 1) / kWavesPerBlock, 1024);
-            HIP_TRY(launch_forward(L, bk.rows_per_lane, bk.emit_mode_fp64, true, true, blocks, s));
+            HIP_TRY(launch_forward(bucket_args(bi, bk.emit_mode_fp64), bk.rows_per_lane, bk.emit_mode_fp64, true, true, blocks, s));
         }
     }
     if (timing) HIP_TRY(hipEventRecord(R->ev[2], s));
     R->computed = true;
     return GATK_PAIRHMM_OK;
+}
+
+// Which wave-group a bucket-local work item belongs to (host copy of the kernel's decoding).
+int group_of_task(const gatk_pairhmm_resident* R, const Bucket& bk, int task) {
+    int lo = bk.desc_begin, hi = bk.desc_begin + bk.num_descs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (R->descs[mid].task_begin <= task) lo = mid; else hi = mid - 1;
+    }
+    const RegionDesc& d = R->descs[lo];
+    return d.group_begin + (task - d.task_begin) % d.num_groups;
 }
 
 // Wait for the stream, turn the device error word into the reference's exception code, fill stats.
@@ -449,14 +555,17 @@ int finish_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     gatk_pairhmm_stats st{};
     st.pairs = R->total_pairs;
     st.cells = R->cells;
-    st.wave_tasks = static_cast<int64_t>(R->tasks.size());
+    st.wave_tasks = R->total_tasks;
+    st.host_plan_ms = R->plan_ms;
+    st.host_upload_ms = R->upload_ms;
     for (size_t bi = 0; bi < R->buckets.size(); ++bi) {
-        const int n = std::min(counters[1 + bi], R->buckets[bi].num_tasks);
+        const Bucket& bk = R->buckets[bi];
+        const int n = std::min(counters[1 + bi], bk.num_tasks);
         st.rerun_tasks += n;
         if (n > 0) {
             std::vector<int32_t> list(n);
-            HIP_TRY(hipMemcpy(list.data(), R->d_rerun_lists.as<int32_t>() + R->buckets[bi].task_begin, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-            for (int t : list) st.rerun_pairs += R->group_segs[R->tasks[R->buckets[bi].task_begin + t].group];
+            HIP_TRY(hipMemcpy(list.data(), R->d_rerun_lists.as<int32_t>() + bk.task_begin, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+            for (int t : list) st.rerun_pairs += R->group_segs[group_of_task(R, bk, t)];
         }
     }
     if (h->timing && g_num_threads.load() == 1 && R->ev[0]) {
@@ -474,13 +583,24 @@ int finish_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
 int download_into(gatk_pairhmm* h, gatk_pairhmm_resident* R, double* const* outs) {
     if (int rc = finish_compute(h, R)) return rc;
     if (R->total_pairs == 0) return GATK_PAIRHMM_OK;
-    // one region, or regions that are contiguous in the caller's memory, need no staging copy
-    std::vector<double> stage;
+    int with_output = 0, last = -1;
+    for (int k = 0; k < R->num_regions; ++k) {
+        if (R->region_out_off[k + 1] == R->region_out_off[k]) continue;
+        if (!outs || !outs[k]) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "likelihoods cannot be null");
+        ++with_output; last = k;
+    }
+    const size_t bytes = static_cast<size_t>(R->total_pairs) * sizeof(double);
+    if (with_output == 1) {  // straight into the caller's array
+        HIP_TRY(hipMemcpy(outs[last], R->d_out.p, bytes, hipMemcpyDeviceToHost));
+        return GATK_PAIRHMM_OK;
+    }
+    // many regions: one device-to-host copy into pinned memory, then scatter on the host
+    HIP_TRY(h->stage_out.ensure(bytes));
+    HIP_TRY(hipMemcpy(h->stage_out.p, R->d_out.p, bytes, hipMemcpyDeviceToHost));
+    const double* src = static_cast<const double*>(h->stage_out.p);
     for (int k = 0; k < R->num_regions; ++k) {
         const int64_t n = R->region_out_off[k + 1] - R->region_out_off[k];
-        if (n == 0) continue;
-        if (!outs || !outs[k]) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "likelihoods cannot be null");
-        HIP_TRY(hipMemcpy(outs[k], R->d_out.as<double>() + R->region_out_off[k], n * sizeof(double), hipMemcpyDeviceToHost));
+        if (n > 0) memcpy(outs[k], src + R->region_out_off[k], static_cast<size_t>(n) * sizeof(double));
     }
     return GATK_PAIRHMM_OK;
 }
@@ -696,6 +816,8 @@ int gatk_pairhmm_close(gatk_pairhmm* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->scratch.release();
+    h->stage_in.release();
+    h->stage_out.release();
     if (h->d_err) (void)hipFree(h->d_err);
     if (h->d_mm) (void)hipFree(h->d_mm);
     if (h->stream) (void)hipStreamDestroy(h->stream);

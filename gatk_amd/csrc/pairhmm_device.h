@@ -25,21 +25,35 @@ enum EmitMode : int {
     kEmitLut5 = 3,      // haplotypes are A/C/G/T/N only: table with an 'N' column
 };
 
-// One lane of a wave-group.  A wave-group packs one or more reads into the 64 lanes of a
-// wavefront: a read of length R takes ceil(R/K) consecutive lanes ("segment"), each lane owning K
-// consecutive read rows; the unused rows are put in FRONT of row 1 so that the read's last row is
-// always row K-1 of the segment's last lane.
-struct LaneDesc {
-    int32_t read_idx;   // read owning this lane, or -1 for an unused lane
-    int32_t first_row;  // 1-based read row of this lane's row 0; <= 0 means leading pad rows
-    int32_t seg_lane;   // lane index inside the segment (0 = segment start)
-    int32_t seg_last;   // 1 if this lane holds the read's last row
+constexpr int kMaxHapLen = 16000;  // one wave's LDS image must fit in a quarter of a 64 KiB block allocation
+
+// A wave-group packs one or more reads into the 64 lanes of a wavefront: a read of length R takes
+// ceil((R + 1) / K) consecutive lanes ("segment"), each lane owning K consecutive read rows; the
+// unused rows are put in FRONT of row 1 so that the read's last row is always row K-1 of the
+// segment's last lane.
+struct SegDesc {
+    int32_t read_idx;    // global read index
+    uint8_t lane_begin;  // first lane of the segment
+    uint8_t seg_lanes;   // lanes in the segment
+    uint16_t reserved;
 };
 
-// One wavefront work item: a wave-group scored against one haplotype.
-struct Task {
-    int32_t group;
-    int32_t hap;
+struct GroupDesc {
+    int32_t seg_begin;  // first SegDesc of the group
+    int16_t num_segs;
+    int16_t fill;       // lanes of the longest segment minus one: extra steps to drain the pipeline
+};
+
+// Work items of one region inside a launch: item t in [task_begin, task_begin + num_groups * num_haps)
+// scores wave-group group_begin + (t - task_begin) % num_groups against haplotype
+// hap_begin + (t - task_begin) / num_groups.  Descriptors are sorted by task_begin.
+struct RegionDesc {
+    int32_t task_begin;
+    int32_t group_begin;
+    int32_t num_groups;
+    int32_t hap_begin;
+    int32_t num_haps;
+    int32_t reserved[3];
 };
 
 // Kernel arguments.  All pointers are device pointers.
@@ -54,16 +68,16 @@ struct DeviceBatch {
     const uint8_t* hap_pool;       // haplotype bytes, each haplotype starting on a 16-byte boundary
     const int32_t* hap_off;        // [num_haps] byte offset into hap_pool
     const int32_t* hap_len;        // [num_haps]
-    const int32_t* hap_local;      // [num_haps] index of the haplotype inside its region
-    const LaneDesc* lanes;         // [num_groups * 64]
-    const int32_t* group_fill;     // [num_groups] lanes of the longest segment minus one
-    const Task* tasks;             // this launch's tasks
-    int32_t num_tasks;
+    const GroupDesc* groups;       // [num_groups]
+    const SegDesc* segs;           // [num_reads with length > 0]
+    const RegionDesc* region_descs;  // this launch's regions
+    int32_t num_region_descs;
+    int32_t num_tasks;             // this launch's work items
     const double* err_prob;        // [256]
     const double* match_to_match;  // [128 * 128]
     double* out;
     int32_t* rerun_count;          // this launch's rerun list length
-    int32_t* rerun_list;           // this launch's rerun list: indices into tasks
+    int32_t* rerun_list;           // this launch's rerun list: work item indices
     int32_t* error_word;
     float fp32_threshold;
     int32_t lds_per_wave;          // bytes of LDS each wave owns

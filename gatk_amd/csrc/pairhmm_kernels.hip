@@ -144,6 +144,14 @@ struct Image {
     static constexpr int kTableBytes = lut_table_bytes(K, MODE);
 };
 
+// What a lane knows about its place in the wave-group.
+struct LaneInfo {
+    int read_idx;   // read owning this lane, or -1 for an unused lane
+    int first_row;  // 1-based read row of this lane's row 0; <= 0 means leading pad rows
+    int seg_lane;   // lane index inside the segment (0 = segment start)
+    int seg_last;   // 1 if this lane holds the read's last row
+};
+
 template <typename T, int K, int MODE>
 __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_idx, unsigned char* slice,
                                          const int lane, const bool queue_underflow) {
@@ -151,15 +159,37 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     constexpr bool kLut = is_lut(MODE);
     constexpr int kCodes = lut_codes(MODE);
     static_assert(!kLut || std::is_same<T, float>::value, "the emission table holds floats");
-    const Task tk = B.tasks[task_idx];
-    const int H = B.hap_len[tk.hap];
-    const int fill = B.group_fill[tk.group];
-    const LaneDesc ld = B.lanes[tk.group * kWave + lane];
+    // ---- which wave-group and haplotype is this work item? (wave-uniform, scalar) ----------------
+    int lo = 0, hi = B.num_region_descs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (B.region_descs[mid].task_begin <= task_idx) lo = mid; else hi = mid - 1;
+    }
+    const RegionDesc rdesc = B.region_descs[lo];
+    const int local = task_idx - rdesc.task_begin;
+    const int hap_local = local / rdesc.num_groups;
+    const int hap_idx = rdesc.hap_begin + hap_local;
+    const GroupDesc grp = B.groups[rdesc.group_begin + (local - hap_local * rdesc.num_groups)];
+    const int H = B.hap_len[hap_idx];
+    const int fill = grp.fill;
+    // ---- which read segment does this lane belong to? ----------------------------------------------
+    LaneInfo ld{-1, 1, 0, 0};
+    for (int k = 0; k < grp.num_segs; ++k) {
+        const SegDesc sd = B.segs[grp.seg_begin + k];
+        const int t = lane - static_cast<int>(sd.lane_begin);
+        if (t >= 0 && t < static_cast<int>(sd.seg_lanes)) {
+            const int len = B.read_off[sd.read_idx + 1] - B.read_off[sd.read_idx];
+            ld.read_idx = sd.read_idx;
+            ld.seg_lane = t;
+            ld.first_row = t * K + 1 - (static_cast<int>(sd.seg_lanes) * K - len);
+            ld.seg_last = (t == static_cast<int>(sd.seg_lanes) - 1) ? 1 : 0;
+        }
+    }
     unsigned char* const hap_img = slice + Image<K, MODE>::kTableBytes;
 
     // ---- haplotype bases -> this wave's LDS image --------------------------------------------
     {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(B.hap_pool + B.hap_off[tk.hap]);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(B.hap_pool + B.hap_off[hap_idx]);
         const int words = (H + 3) >> 2;
         if (kLut) {
             // every entry the sweep can touch must hold a valid table offset: zero the pads
@@ -376,7 +406,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     bool under = false;
     if (ld.seg_last != 0 && ld.read_idx >= 0) {
         const double res = ::log10(static_cast<double>(w.acc)) - Scale<T>::kExp2 * 0.30102999566398119521;
-        B.out[B.read_out_base[ld.read_idx] + B.hap_local[tk.hap]] = res;
+        B.out[B.read_out_base[ld.read_idx] + hap_local] = res;
         // too small for fp32 to be trusted, or NaN / infinity from the scaled form: redo in fp64
         if (kScaled) under = !(static_cast<float>(w.acc) >= B.fp32_threshold && static_cast<float>(w.acc) <= 3.0e38f);
     }

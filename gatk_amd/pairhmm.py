@@ -56,7 +56,8 @@ class CBatch(C.Structure):
 
 class CStats(C.Structure):
     _fields_ = [("pairs", C.c_int64), ("cells", C.c_int64), ("wave_tasks", C.c_int64), ("rerun_tasks", C.c_int64),
-                ("rerun_pairs", C.c_int64), ("fp32_kernel_ms", C.c_double), ("fp64_kernel_ms", C.c_double)]
+                ("rerun_pairs", C.c_int64), ("fp32_kernel_ms", C.c_double), ("fp64_kernel_ms", C.c_double),
+                ("host_plan_ms", C.c_double), ("host_upload_ms", C.c_double)]
 
 
 # every symbol include/gatk_pairhmm.h declares

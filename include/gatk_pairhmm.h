@@ -67,6 +67,8 @@ typedef struct gatk_pairhmm_stats {
     int64_t rerun_pairs;    /* pairs covered by the recomputed work items */
     double fp32_kernel_ms;  /* device time of the fp32 forward kernels (HIP events), 0 if not timed */
     double fp64_kernel_ms;  /* device time of the fp64 rerun kernels (HIP events), 0 if not timed */
+    double host_plan_ms;    /* host time spent checking, planning and packing the call */
+    double host_upload_ms;  /* host time of the single host-to-device copy (including the wait for it) */
 } gatk_pairhmm_stats;
 
 /* Constructor of a PairHMM instance on GPU `device` (replaces the JNI library's one-time

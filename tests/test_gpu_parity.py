@@ -324,3 +324,48 @@ def test_cxx_host_mirror():
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gatk_amd", "cxx_driver")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "cxx_driver ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_zero_match_to_match_rows_go_through_fp64(hmm, oracle):
+    """Insertion and deletion quality both <= 3 clamp matchToMatch to 0 (PairHMMModel.java:119): the fp32
+    pass divides by it, must notice the NaN and hand the work item to the fp64 pass."""
+    rng = np.random.default_rng(17)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    hap = acgt[rng.integers(0, 4, 120)]
+    reads = []
+    for k in range(12):
+        n = 40 + k
+        start = int(rng.integers(0, 120 - n))
+        ins = rng.integers(20, 46, n)
+        dele = rng.integers(20, 46, n)
+        if k % 2 == 0:  # every other read has a stretch of rows with t0 = 0 (and one at the first row)
+            ins[0] = dele[0] = 0
+            ins[10:14] = rng.integers(0, 4, 4)
+            dele[10:14] = rng.integers(0, 4, 4)
+        reads.append((hap[start:start + n], rng.integers(10, 41, n), ins, dele, [10] * n))
+    b = pack(reads, [hap, hap[::-1].copy()])
+    want = ref(oracle, b, 1)
+    got = hmm.compute_batch(b)
+    assert hmm.stats()["rerun_tasks"] > 0
+    assert_parity(got, want)
+    hmm.set_option("emit_mode", 0)  # and through the byte-compare kernel variant
+    try:
+        assert_parity(hmm.compute_batch(b), want)
+    finally:
+        hmm.set_option("emit_mode", -1)
+
+
+def test_extreme_gap_quality_steps(hmm, oracle):
+    """Insertion quality jumping between 1 and 127 from row to row stretches the rescaled fp32 form
+    (F = I / t2) over ~12 decades; whatever fp32 cannot hold must come back through the fp64 pass."""
+    rng = np.random.default_rng(18)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    hap = acgt[rng.integers(0, 4, 200)]
+    reads = []
+    for k in range(8):
+        n = 90
+        ins = np.where(np.arange(n) % 2 == 0, 127, 4 + k)
+        dele = np.where(np.arange(n) % 3 == 0, 4, 127)
+        reads.append((hap[20 + k:20 + k + n], rng.integers(5, 41, n), ins, dele, rng.integers(1, 60, n)))
+    b = pack(reads, [hap, hap[10:150]])
+    assert_parity(hmm.compute_batch(b), ref(oracle, b, 1))
