@@ -15,7 +15,7 @@ import numpy as np
 from .batch import Batch, pack
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgatk_pairhmm_hip.so")
+LIB_PATH = os.environ.get("GATK_PAIRHMM_LIB", os.path.join(_HERE, "libgatk_pairhmm_hip.so"))  # override: experimental builds
 
 OK, ILLEGAL_ARGUMENT, ILLEGAL_STATE, INDEX_OUT_OF_BOUNDS, DEVICE_ERROR, OUT_OF_MEMORY = range(6)
 

@@ -48,7 +48,7 @@ def main():
         t0 = time.time()
         b = synth.config_c3(num_reads=nreads, num_haps=nhaps)
         t1 = time.time()
-        for k in (0, 5, 6, 7, 8, 10, 12, 16, -8):
+        for k in (0, 6, 8, 10, 12, 16, 5, 7):
             hmm.set_option("emit_mode", 0 if k < 0 else -1)
             k = abs(k)
             hmm.set_option("force_rows_per_lane", k)

@@ -14,6 +14,12 @@ __device__ inline float shr1(float v, float old) {
     return __builtin_bit_cast(float, r);
 }
 
+template <int CTRL>
+__device__ inline float dpp_mov(float v) {
+    int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(float, r);
+}
+
 __global__ void k_dpp_check(float* out) {
     float v = (float)threadIdx.x;
     out[threadIdx.x] = shr1(v, -1.0f);
@@ -72,6 +78,69 @@ __global__ void __launch_bounds__(256) k_rate(float* out, int iters, float a, fl
                 x0 = (x1 > b ? a : b) * x0; x1 = (x2 > b ? a : b) * x1; x2 = (x3 > b ? a : b) * x2; x3 = (x0 > b ? a : b) * x3;
             }
         }
+    }
+    else if (MODE == 8) {  // row_shr:1 (within rows of 16 lanes) then dependent fma, 4 chains, VGPR operands
+        float y0 = x4, y1 = x5, z0 = x6, z1 = x7;
+        asm volatile("" : "+v"(y0), "+v"(y1), "+v"(z0), "+v"(z1));
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                x0 = __builtin_fmaf(dpp_mov<0x111>(x0), y0, z0); x1 = __builtin_fmaf(dpp_mov<0x111>(x1), y1, z1);
+                x2 = __builtin_fmaf(dpp_mov<0x111>(x2), y0, z1); x3 = __builtin_fmaf(dpp_mov<0x111>(x3), y1, z0);
+            }
+        }
+    } else if (MODE == 9) {  // wave_shr:1 then dependent fma, 4 chains, VGPR operands
+        float y0 = x4, y1 = x5, z0 = x6, z1 = x7;
+        asm volatile("" : "+v"(y0), "+v"(y1), "+v"(z0), "+v"(z1));
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                x0 = __builtin_fmaf(dpp_mov<0x138>(x0), y0, z0); x1 = __builtin_fmaf(dpp_mov<0x138>(x1), y1, z1);
+                x2 = __builtin_fmaf(dpp_mov<0x138>(x2), y0, z1); x3 = __builtin_fmaf(dpp_mov<0x138>(x3), y1, z0);
+            }
+        }
+    } else if (MODE == 10) {  // no shift: the same 4 dependent fma chains (baseline for 8 and 9)
+        float y0 = x4, y1 = x5, z0 = x6, z1 = x7;
+        asm volatile("" : "+v"(y0), "+v"(y1), "+v"(z0), "+v"(z1));
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                x0 = __builtin_fmaf(x0, y0, z0); x1 = __builtin_fmaf(x1, y1, z1);
+                x2 = __builtin_fmaf(x2, y0, z1); x3 = __builtin_fmaf(x3, y1, z0);
+            }
+        }
+    } else if (MODE == 11) {  // ds_bpermute shift (LDS crossbar, no VALU) then dependent fma, 4 chains
+        float y0 = x4, y1 = x5, z0 = x6, z1 = x7;
+        const int src = (((int)threadIdx.x & 63) - 1) * 4;
+        asm volatile("" : "+v"(y0), "+v"(y1), "+v"(z0), "+v"(z1));
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                x0 = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, x0))), y0, z0);
+                x1 = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, x1))), y1, z1);
+                x2 = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, x2))), y0, z1);
+                x3 = __builtin_fmaf(__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, x3))), y1, z0);
+            }
+        }
+    }
+    else if (MODE == 12) {  // packed cell pattern: the 5-instruction cell on float2 values, 4 independent cell pairs
+        typedef float v2 __attribute__((ext_vector_type(2)));
+        v2 p0 = {x0, x1}, p1 = {x1, x2}, p2 = {x2, x3}, p3 = {x3, x4};
+        v2 c0 = {a + x4 * 1e-6f, a + x5 * 1e-6f}, c1 = {b + x5 * 1e-6f, b + x6 * 1e-6f}, c2 = {a * 0.5f + x6 * 1e-6f, a * 0.5f}, c3 = {b * 0.5f + x7 * 1e-6f, b * 0.5f};
+        v2 E0 = 1, E1 = 1, E2 = 1, E3 = 1, F0 = 1, F1 = 1, F2 = 1, F3 = 1, S0 = 1, S1 = 1, S2 = 1, S3 = 1, M0 = 1, M1 = 1, M2 = 1, M3 = 1;
+        asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                v2 m0 = p0 * S0, m1 = p1 * S1, m2 = p2 * S2, m3 = p3 * S3;
+                E0 = __builtin_elementwise_fma(E0, c0, M0); E1 = __builtin_elementwise_fma(E1, c1, M1); E2 = __builtin_elementwise_fma(E2, c2, M2); E3 = __builtin_elementwise_fma(E3, c3, M3);
+                F0 = __builtin_elementwise_fma(F0, c1, m0); F1 = __builtin_elementwise_fma(F1, c2, m1); F2 = __builtin_elementwise_fma(F2, c3, m2); F3 = __builtin_elementwise_fma(F3, c0, m3);
+                S0 = __builtin_elementwise_fma(E0, c2, __builtin_elementwise_fma(F0, c3, m0)); S1 = __builtin_elementwise_fma(E1, c3, __builtin_elementwise_fma(F1, c0, m1));
+                S2 = __builtin_elementwise_fma(E2, c0, __builtin_elementwise_fma(F2, c1, m2)); S3 = __builtin_elementwise_fma(E3, c1, __builtin_elementwise_fma(F3, c2, m3));
+                M0 = m0; M1 = m1; M2 = m2; M3 = m3;
+            }
+        }
+        x0 = S0.x + E0.y + F0.x; x1 = S1.x + E1.y + F1.x; x2 = S2.y + E2.x + F2.y; x3 = S3.x + E3.x + F3.y;
     }
     else if (MODE == 6) {  // 8 independent v_fma_f32 chains, all three operands in VGPRs
         float y0 = x0 * 0.5f, y1 = x1 * 0.5f, y2 = x2 * 0.5f, y3 = x3 * 0.5f, z0 = a + x0, z1 = a + x1, z2 = b + x2, z3 = b + x3;
@@ -143,6 +212,11 @@ int main() {
     if (run_rate<3>("dpp_shr1+fma x4 indep", 64, 1, d_out)) return 1;
     if (run_rate<4>("v_fma_f32 dependent chain", 64, 2, d_out)) return 1;
     if (run_rate<5>("cmp+cndmask+mul x4", 96, 1.0 / 3, d_out)) return 1;
+    if (run_rate<12>("packed cell pattern 5 pk x4", 80, 3.6, d_out)) return 1;
+    if (run_rate<10>("4 chains fma (no shift)", 32, 2, d_out)) return 1;
+    if (run_rate<8>("4 chains row_shr:1 + fma", 32, 2, d_out)) return 1;
+    if (run_rate<9>("4 chains wave_shr:1 + fma", 32, 2, d_out)) return 1;
+    if (run_rate<11>("4 chains ds_bpermute + fma", 32, 2, d_out)) return 1;
     if (run_rate<6>("v_fma_f32 x8 indep 3 VGPR ops", 64, 2, d_out)) return 1;
     if (run_rate<7>("cell pattern 5 instr x4 cells", 80, 1.8, d_out)) return 1;
     printf("done\n");
