@@ -24,6 +24,7 @@ hipError_t launch_forward(const DeviceBatch& B, int rows_per_lane, int emit_mode
                           int blocks, hipStream_t stream);
 int lds_bytes_per_wave(int rows_per_lane, int emit_mode, int max_hap_len);
 hipError_t launch_validate(const DeviceBatch& B, hipStream_t stream);
+hipError_t launch_expand_reads(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_fill_neg_inf(double* out, const int32_t* idx, int n, hipStream_t stream);
 }  // namespace pairhmm_hip
 
@@ -120,11 +121,12 @@ struct gatk_pairhmm_resident {
     // ---- device ----
     DevBuf d_arena;  // every input array of the call, one H2D copy
     DevBuf d_out, d_rerun_lists, d_counters;
+    DevBuf d_row_consts;  // fp32 row constants of every read, written on the device
     DeviceBatch base{};  // pointers into d_arena
     const int32_t* d_neg_inf_idx = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     void release() {
-        for (DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_counters}) b->release();
+        for (DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_counters, &d_row_consts}) b->release();
         for (auto& e : ev)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
     }
@@ -170,14 +172,14 @@ double now_ms() {
 // so whether the GPU is full is a property of the call, not of one region.
 int choose_rows_per_lane(int max_read_len, int64_t num_reads, int64_t num_haps, double mean_hap_len, int64_t call_pairs,
                          int forced) {
-    const int min_k = (max_read_len + kWave) / kWave;  // lanes * k >= len + 1
+    const int min_k = (max_read_len + 1 + kWave) / kWave;  // lanes * k >= len + 2 (a pad row in front, the sum row behind)
     if (forced >= min_k && rows_per_lane_supported(forced)) return forced;
     int best_k = kMaxRowsPerLane;
     double best = std::numeric_limits<double>::infinity();
     for (int k : kRowsPerLaneChoices) {
         if (k < min_k) continue;
         if (k > 10 && best_k != kMaxRowsPerLane) break;  // beyond 10 rows the fp64 rerun kernel spills: only for long reads
-        const int lanes = (max_read_len + k) / k;
+        const int lanes = (max_read_len + 1 + k) / k;
         const int per_wave = std::max(1, kWave / lanes);
         const double tasks = std::ceil(static_cast<double>(num_reads) / per_wave) * static_cast<double>(num_haps);
         const double steps = mean_hap_len + lanes - 1;
@@ -216,9 +218,9 @@ int check_region(const gatk_pairhmm_batch& b, int k) {
     for (int a = 0; a < b.num_haps; ++a)
         if (b.hap_offsets[a + 1] - b.hap_offsets[a] == 0)
             return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("zero-length haplotype: the reference result is undefined") + where);
-    if (read_max > kWave * kMaxRowsPerLane - 1)
+    if (read_max > kWave * kMaxRowsPerLane - 2)
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "readBases is too long, got " + std::to_string(read_max) + " but max is " +
-                                                       std::to_string(kWave * kMaxRowsPerLane - 1) + where);
+                                                       std::to_string(kWave * kMaxRowsPerLane - 2) + where);
     if (hap_max > kMaxHapLen)
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "Haplotype bases is too long, got " + std::to_string(hap_max) + " but max is " +
                                                        std::to_string(kMaxHapLen) + where);
@@ -329,9 +331,9 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             while (pos < order.size()) {
                 const int r = order[pos];
                 const int len = b.read_offsets[r + 1] - b.read_offsets[r];
-                const int seg = (len + K) / K;  // rows >= len + 1: every segment starts with a pad row
+                const int seg = (len + 1 + K) / K;  // rows >= len + 2: a pad row in front, the sum row behind
                 if (used + seg > kWave) break;
-                segs.push_back(SegDesc{rp.read_begin + r, static_cast<uint8_t>(used), static_cast<uint8_t>(seg), 0});
+                segs.push_back(SegDesc{rp.read_begin + r, static_cast<uint8_t>(used), static_cast<uint8_t>(seg), static_cast<uint16_t>(len)});
                 used += seg;
                 max_seg = std::max(max_seg, seg);
                 ++g.num_segs; ++pos;
@@ -463,6 +465,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     HIP_TRY(R->d_out.ensure(std::max<size_t>(static_cast<size_t>(call_pairs) * sizeof(double), 16)));
     HIP_TRY(R->d_rerun_lists.ensure(std::max<size_t>(static_cast<size_t>(total_tasks) * sizeof(int32_t), 16)));
     HIP_TRY(R->d_counters.ensure(256));
+    HIP_TRY(R->d_row_consts.ensure((rbytes + 2 * static_cast<size_t>(total_reads) + 2) * sizeof(RowConst)));
     if (L.size) HIP_TRY(hipMemcpyAsync(R->d_arena.p, S, L.size, hipMemcpyHostToDevice, s));
     const uint8_t* D = R->d_arena.as<uint8_t>();
     DeviceBatch& B = R->base;
@@ -477,6 +480,8 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     B.segs = reinterpret_cast<const SegDesc*>(D + o_segs);
     B.region_descs = reinterpret_cast<const RegionDesc*>(D + o_descs);
     B.total_read_bytes = total_read_bytes;
+    B.num_reads = static_cast<int32_t>(total_reads);
+    B.row_consts = R->d_row_consts.as<RowConst>();
     R->d_neg_inf_idx = reinterpret_cast<const int32_t*>(D + o_neg);
     // the staging buffer is reused by the next upload on this handle: finish the copy first
     HIP_TRY(hipStreamSynchronize(s));
@@ -503,6 +508,7 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     B.error_word = R->d_counters.as<int32_t>();
     B.fp32_threshold = h->fp32_threshold;
     HIP_TRY(launch_validate(B, s));
+    if (!h->force_fp64) HIP_TRY(launch_expand_reads(B, s));
     if (R->num_neg_inf > 0) HIP_TRY(launch_fill_neg_inf(B.out, R->d_neg_inf_idx, R->num_neg_inf, s));
     if (timing) HIP_TRY(hipEventRecord(R->ev[0], s));
     auto bucket_args = [&](size_t bi, int mode) {

@@ -35,8 +35,25 @@ struct SegDesc {
     int32_t read_idx;    // global read index
     uint8_t lane_begin;  // first lane of the segment
     uint8_t seg_lanes;   // lanes in the segment
-    uint16_t reserved;
+    uint16_t read_len;
 };
+
+// Constants of one matrix row in the fp32 (rescaled) arithmetic, expanded from a read's quality
+// bytes once per read and call (the reference expands them once per read too:
+// PairHMM.java:210-222 keeps one read against all haplotypes).  Read r owns entries
+// [read_off[r] + 2 r, read_off[r + 1] + 2 (r + 1)): entry 0 is the pad row above row 1, entries
+// 1..R are the read's rows, entry R + 1 is the sum row.
+struct RowConst {
+    float p_match;     // prior of a matching base times the row's matchToMatch
+    float p_mismatch;  // prior of a mismatching base times the row's matchToMatch
+    float t5;          // deletionToDeletion
+    float c_f;         // matchToInsertion * insertionToInsertion' / matchToInsertion'   (' = next row)
+    float c_i;         // matchToInsertion * indelToMatch' / matchToMatch'
+    float c_e;         // matchToDeletion * indelToMatch' / matchToMatch'
+    uint32_t base;     // read base, or 0x100 for a row that matches nothing / everything alike
+    uint32_t reserved;
+};
+static_assert(sizeof(RowConst) == 32, "two 16-byte loads per row");
 
 struct GroupDesc {
     int32_t seg_begin;  // first SegDesc of the group
@@ -71,6 +88,8 @@ struct DeviceBatch {
     const GroupDesc* groups;       // [num_groups]
     const SegDesc* segs;           // [num_reads with length > 0]
     const RegionDesc* region_descs;  // this launch's regions
+    RowConst* row_consts;          // [total_read_bytes + 2 * num_reads], written by the expansion kernel
+    int32_t num_reads;
     int32_t num_region_descs;
     int32_t num_tasks;             // this launch's work items
     const double* err_prob;        // [256]

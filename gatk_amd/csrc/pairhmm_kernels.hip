@@ -39,6 +39,23 @@
 
 namespace pairhmm_hip {
 
+// Profiling build only (make phase): shader-clock cycles each wave spends in the phases of a task,
+// summed over waves.  0 decode+haplotype image, 1 row constants+table, 2 fill, 3 steady, 4 drain,
+// 5 termination, 6 tasks.
+#ifdef PAIRHMM_PHASE_CLOCKS
+__device__ unsigned long long g_phase_clocks[8];
+#define PHASE_BEGIN() long long phase_t0 = clock64()
+#define PHASE_END(n)                                                                         \
+    do {                                                                                     \
+        const long long phase_t1 = clock64();                                                \
+        if (lane == 0) atomicAdd(&g_phase_clocks[n], (unsigned long long)(phase_t1 - phase_t0)); \
+        phase_t0 = phase_t1;                                                                 \
+    } while (0)
+#else
+#define PHASE_BEGIN() do {} while (0)
+#define PHASE_END(n) do {} while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ float shr1(float v) {
@@ -97,8 +114,7 @@ struct Rows {
     T T5[K];
     T A[K], B[K], C[K], D[K], E[K];  // plain: t0', t1', t2', t3', t4*t1'   scaled: cF, cI, cE, -, -
     T Ml[K], El[K], Sd[K];
-    T T2L;  // scaled: t2 of the lane's last row (I = F * t2 in the final sum)
-    T Sout, Iout, acc;
+    T Sout, Iout;
 };
 
 template <typename T> struct IsScaled { static constexpr bool value = false; };
@@ -118,11 +134,9 @@ __device__ __forceinline__ void column(Rows<T, K>& w, const T (&prior)[K], const
         if (IsScaled<T>::value) {
             In = fma_(Iup, w.A[r], M);
             Sn = fma_(E, w.C[r], fma_(Iup, w.B[r], M));
-            if (r == K - 1) w.acc = fma_(Iup, w.T2L, w.acc + M);
         } else {
             In = fma_(M, w.C[r], Iup * w.D[r]);
             Sn = fma_(E, w.E[r], fma_(Iup, w.B[r], M * w.A[r]));
-            if (r == K - 1) w.acc += M + Iup;
         }
         w.Ml[r] = M;
         w.El[r] = E;
@@ -159,6 +173,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     constexpr bool kLut = is_lut(MODE);
     constexpr int kCodes = lut_codes(MODE);
     static_assert(!kLut || std::is_same<T, float>::value, "the emission table holds floats");
+    PHASE_BEGIN();
     // ---- which wave-group and haplotype is this work item? (wave-uniform, scalar) ----------------
     int lo = 0, hi = B.num_region_descs - 1;
     while (lo < hi) {
@@ -178,10 +193,10 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
         const SegDesc sd = B.segs[grp.seg_begin + k];
         const int t = lane - static_cast<int>(sd.lane_begin);
         if (t >= 0 && t < static_cast<int>(sd.seg_lanes)) {
-            const int len = B.read_off[sd.read_idx + 1] - B.read_off[sd.read_idx];
+            const int len = sd.read_len;
             ld.read_idx = sd.read_idx;
             ld.seg_lane = t;
-            ld.first_row = t * K + 1 - (static_cast<int>(sd.seg_lanes) * K - len);
+            ld.first_row = t * K + 1 - (static_cast<int>(sd.seg_lanes) * K - len - 1);  // pads | rows 1..len | sum row
             ld.seg_last = (t == static_cast<int>(sd.seg_lanes) - 1) ? 1 : 0;
         }
     }
@@ -213,10 +228,17 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
         }
     }
 
+    PHASE_END(0);
     // ---- per-row constants ---------------------------------------------------------------------
     // Every segment starts with at least one pad row.  A pad row behaves as matrix row 0
     // (M = I = 0, D = scale / H in every column) whatever the lane above hands down, so the value
     // a segment's first lane receives from the previous segment never reaches a real row.
+    //
+    // Every segment ends with a sum row (row R + 1, always row K-1 of the segment's last lane).  Read
+    // row R hands it Sn = M[R][j] + I[R][j]; with emission 1 and a deletion-to-deletion weight of 1
+    // its M is that hand-off one column later and its E is the running sum of its M, so after the
+    // last column  sum_j (M[R][j] + I[R][j]) = E + M + (the hand-off still waiting in Sd).  The final
+    // sum therefore costs no instruction in the sweep.
     const T initD = static_cast<T>(::ldexp(1.0, Scale<T>::kExp2) / static_cast<double>(H));
     int ro = 0, R = 0;
     if (ld.read_idx >= 0) {
@@ -226,85 +248,105 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     Rows<T, K> w;
     unsigned XB[K];
     T P[K], Q[K];
-    w.T2L = static_cast<T>(0);
+    if constexpr (kScaled) {
+        // expanded once per read by expand_reads: two 16-byte loads per row, no branches, every
+        // load of the lane in flight at once
+        const int rc_base = ro + 2 * (ld.read_idx >= 0 ? ld.read_idx : 0);
+        float4 c0[K], c1[K];
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
-        const int i = ld.first_row + r;  // 1-based read row; <= 0: pad row
-        double p = 0, q = 0, t0 = 1, t2 = 0, t4 = 0, t5 = 0, t0n = 0, t1n = 0, t2n = 0, t3n = 0;
-        bool pad = false, has_next = false;
-        unsigned xb = kNoBase;
-        if (ld.read_idx >= 0) {
-            if (i >= 1) {
-                const unsigned x = B.read_bases[ro + i - 1];
-                const double e = B.err_prob[B.read_quals[ro + i - 1]];
-                const unsigned ins = B.ins_gop[ro + i - 1] & 127u, del = B.del_gop[ro + i - 1] & 127u;
-                xb = x;
-                p = 1.0 - e;                         // QualityUtils.qualToProb
-                q = (x == 'N') ? p : e / 3.0;        // a read 'N' matches every base
-                t0 = B.match_to_match[ins * 128u + del];
-                t2 = B.err_prob[ins];                // matchToInsertion
-                t4 = B.err_prob[del];                // matchToDeletion
-                t5 = B.err_prob[B.gcp[ro + i - 1]];  // deletionToDeletion
+        for (int r = 0; r < K; ++r) {
+            int e = ld.first_row + r;
+            e = e < 0 ? 0 : (e > R + 1 ? R + 1 : e);
+            const float4* src = reinterpret_cast<const float4*>(B.row_consts + rc_base + e);
+            c0[r] = src[0];
+            c1[r] = src[1];
+        }
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int i = ld.first_row + r;
+            const bool used = ld.read_idx >= 0;
+            const bool deep_pad = i < 0;  // the row below is a pad row too: hand down anything finite
+            P[r] = (used && !deep_pad) ? c0[r].x : 0.0f;
+            Q[r] = (used && !deep_pad) ? c0[r].y : 0.0f;
+            w.T5[r] = !used ? 0.0f : deep_pad ? 1.0f : c0[r].z;
+            w.A[r] = (used && !deep_pad) ? c0[r].w : 0.0f;
+            w.B[r] = (used && !deep_pad) ? c1[r].x : 0.0f;
+            w.C[r] = !used ? 0.0f : deep_pad ? 1.0f : c1[r].y;
+            XB[r] = (used && !deep_pad) ? __float_as_uint(c1[r].z) : kNoBase;
+            pin(w.A[r]); pin(w.B[r]); pin(w.C[r]); pin(w.T5[r]);
+            w.Ml[r] = 0.0f;
+            w.El[r] = (used && i <= 0) ? initD : 0.0f;  // column 0
+            if (kLut) {
+                // emission table: entry [r / 2][code][lane][r % 2] = prior of row r against base code
+                float* tbl = reinterpret_cast<float*>(slice);
+                const unsigned letters[5] = {'A', 'C', 'T', 'G', 'N'};
+#pragma unroll
+                for (int c = 0; c < kCodes; ++c)
+                    tbl[(((r >> 1) * kCodes + c) * kWave + lane) * 2 + (r & 1)] = (XB[r] == letters[c] || c == 4) ? P[r] : Q[r];
             } else {
-                pad = true;
-                t4 = 1.0;
-                t5 = 1.0;
-                if (i < 0) { t0n = 1.0; t1n = 1.0; }  // next row is a pad row too: anything finite
-            }
-            if (i >= 0 && i < R) {  // transitions of read row i+1, taken from quals[i]
-                const unsigned ins = B.ins_gop[ro + i] & 127u, del = B.del_gop[ro + i] & 127u;
-                const double eg = B.err_prob[B.gcp[ro + i]];
-                has_next = true;
-                t0n = B.match_to_match[ins * 128u + del];
-                t1n = 1.0 - eg;          // indelToMatch
-                t2n = B.err_prob[ins];   // matchToInsertion
-                t3n = eg;                // insertionToInsertion
+                pin(XB[r]); pin(P[r]); pin(Q[r]);
             }
         }
-        const bool real_next = has_next && i >= 1;
-        XB[r] = xb;
-        w.T5[r] = static_cast<T>(t5);
-        if (kScaled) {
-            P[r] = static_cast<T>(p * t0);
-            Q[r] = static_cast<T>(q * t0);
-            w.A[r] = static_cast<T>(real_next ? t2 * t3n / t2n : 0.0);
-            w.B[r] = static_cast<T>(real_next ? t2 * t1n / t0n : 0.0);
-            w.C[r] = static_cast<T>((has_next || pad) ? t4 * t1n / t0n : 0.0);
-            if (r == K - 1) w.T2L = static_cast<T>(t2);
-            pin(w.A[r]); pin(w.B[r]); pin(w.C[r]);
-        } else {
+    } else {
+        // plain form, straight from the quality bytes (rare: only pairs the fp32 pass gave up on)
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int i = ld.first_row + r;  // 1-based read row; <= 0: pad row
+            double p = 0, q = 0, t4 = 0, t5 = 0, t0n = 0, t1n = 0, t2n = 0, t3n = 0;
+            bool pad = false, has_next = false;
+            unsigned xb = kNoBase;
+            const bool sum_row = ld.read_idx >= 0 && i == R + 1;
+            const bool last_row = ld.read_idx >= 0 && i == R;
+            if (sum_row) {
+                p = q = 1.0;
+                t5 = 1.0;
+            } else if (ld.read_idx >= 0) {
+                if (i >= 1) {
+                    const unsigned x = B.read_bases[ro + i - 1];
+                    const double e = B.err_prob[B.read_quals[ro + i - 1]];
+                    xb = x;
+                    p = 1.0 - e;                         // QualityUtils.qualToProb
+                    q = (x == 'N') ? p : e / 3.0;        // a read 'N' matches every base
+                    t4 = B.err_prob[B.del_gop[ro + i - 1] & 127u];  // matchToDeletion
+                    t5 = B.err_prob[B.gcp[ro + i - 1]];             // deletionToDeletion
+                } else {
+                    pad = true;
+                    t4 = 1.0;
+                    t5 = 1.0;
+                    if (i < 0) t1n = 1.0;  // next row is a pad row too: anything finite
+                }
+                if (i >= 0 && i < R) {  // transitions of read row i+1, taken from quals[i]
+                    const unsigned ins = B.ins_gop[ro + i] & 127u, del = B.del_gop[ro + i] & 127u;
+                    const double eg = B.err_prob[B.gcp[ro + i]];
+                    has_next = true;
+                    t0n = B.match_to_match[ins * 128u + del];
+                    t1n = 1.0 - eg;          // indelToMatch
+                    t2n = B.err_prob[ins];   // matchToInsertion
+                    t3n = eg;                // insertionToInsertion
+                }
+            }
+            const bool real_next = has_next && i >= 1;
+            XB[r] = xb;
             P[r] = static_cast<T>(p);
             Q[r] = static_cast<T>(q);
-            w.A[r] = static_cast<T>(real_next ? t0n : 0.0);
-            w.B[r] = static_cast<T>(t1n);
+            w.T5[r] = static_cast<T>(t5);
+            w.A[r] = static_cast<T>(real_next ? t0n : last_row ? 1.0 : 0.0);  // last row: Sn = M + I
+            w.B[r] = static_cast<T>(last_row ? 1.0 : t1n);
             w.C[r] = static_cast<T>(real_next ? t2n : 0.0);
             w.D[r] = static_cast<T>(real_next ? t3n : 0.0);
             w.E[r] = static_cast<T>(t4 * t1n);
-            pin(w.A[r]); pin(w.B[r]); pin(w.C[r]); pin(w.D[r]); pin(w.E[r]);
-        }
-        w.Ml[r] = static_cast<T>(0);
-        w.El[r] = pad ? initD : static_cast<T>(0);  // column 0
-        pin(w.T5[r]);
-        if (kLut) {
-            // emission table: entry [r / 2][code][lane][r % 2] = prior of row r against base code
-            float* tbl = reinterpret_cast<float*>(slice);
-            const unsigned letters[5] = {'A', 'C', 'T', 'G', 'N'};
-#pragma unroll
-            for (int c = 0; c < kCodes; ++c)
-                tbl[(((r >> 1) * kCodes + c) * kWave + lane) * 2 + (r & 1)] =
-                    static_cast<float>((xb == letters[c] || c == 4) ? P[r] : Q[r]);
-        } else {
+            pin(w.A[r]); pin(w.B[r]); pin(w.C[r]); pin(w.D[r]); pin(w.E[r]); pin(w.T5[r]);
             pin(XB[r]); pin(P[r]); pin(Q[r]);
+            w.Ml[r] = static_cast<T>(0);
+            w.El[r] = pad ? initD : static_cast<T>(0);  // column 0
         }
     }
-    pin(w.T2L);
     // column-0 hand-offs: Sn of the row above, where M = I = 0
     const T* cS = kScaled ? w.C : w.E;
 #pragma unroll
     for (int r = 1; r < K; ++r) w.Sd[r] = w.El[r - 1] * cS[r - 1];
     w.Sout = w.El[K - 1] * cS[K - 1];
     w.Iout = static_cast<T>(0);
-    w.acc = static_cast<T>(0);
     w.Sd[0] = shr1(w.Sout);
     __builtin_amdgcn_wave_barrier();
 
@@ -315,6 +357,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     //   [max(H, fill), H+fill) pipeline drain: lanes with s - t >= H are done  -> masked
     const int steady_begin = fill < H ? fill : H;
     int s = 0;
+    PHASE_END(1);
     if (kLut) {
         const uint16_t* hp = reinterpret_cast<const uint16_t*>(hap_img) + (kHapFrontPad - ld.seg_lane);
         const unsigned char* tbl_lane = slice + lane * 8;
@@ -334,6 +377,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
             if (static_cast<unsigned>(step - ld.seg_lane) < static_cast<unsigned>(H)) column<T, K>(w, prior, Sin, Iin);
         };
         for (; s < steady_begin; ++s) masked_step(s);
+        PHASE_END(2);
         if (s + 4 <= H) {
             // two-deep software pipeline: emission terms of the next four columns and base codes of
             // the four after them are in flight while the current four columns are computed
@@ -361,7 +405,9 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
                     for (int r = 0; r < K; ++r) pc[u][r] = pn[u][r];
             }
         }
+        PHASE_END(3);
         for (; s < H + fill; ++s) masked_step(s);
+        PHASE_END(4);
     } else {
         const unsigned char* hp = hap_img + (kHapFrontPad - ld.seg_lane);
         auto emit = [&](const unsigned yb, T (&prior)[K]) {
@@ -405,10 +451,11 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     // ---- termination ---------------------------------------------------------------------------
     bool under = false;
     if (ld.seg_last != 0 && ld.read_idx >= 0) {
-        const double res = ::log10(static_cast<double>(w.acc)) - Scale<T>::kExp2 * 0.30102999566398119521;
+        const T total = w.El[K - 1] + w.Ml[K - 1] + w.Sd[K - 1];  // the sum row, see above
+        const double res = ::log10(static_cast<double>(total)) - Scale<T>::kExp2 * 0.30102999566398119521;
         B.out[B.read_out_base[ld.read_idx] + hap_local] = res;
         // too small for fp32 to be trusted, or NaN / infinity from the scaled form: redo in fp64
-        if (kScaled) under = !(static_cast<float>(w.acc) >= B.fp32_threshold && static_cast<float>(w.acc) <= 3.0e38f);
+        if (kScaled) under = !(static_cast<float>(total) >= B.fp32_threshold && static_cast<float>(total) <= 3.0e38f);
     }
     if (queue_underflow) {
         if (__any(under ? 1 : 0)) {
@@ -418,6 +465,10 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
             }
         }
     }
+    PHASE_END(5);
+#ifdef PAIRHMM_PHASE_CLOCKS
+    if (lane == 0) atomicAdd(&g_phase_clocks[6], 1ull);
+#endif
 }
 
 // One task per wave, tasks taken in launch order.
@@ -445,6 +496,53 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_list(const DeviceBa
         const int task = __builtin_amdgcn_readfirstlane(B.rerun_list[it]);
         run_task<T, K, MODE>(B, task, lds + wave * B.lds_per_wave, lane, false);
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Read expansion for the fp32 pass: one wave per read, one lane per RowConst entry.  The arithmetic
+// is done in double and rounded once, so an entry holds exactly what the forward kernel would have
+// derived from the quality bytes (PairHMMModel.java:109-143 for the transitions,
+// QualityUtils.java:169-176 for the priors).
+__global__ void __launch_bounds__(256) expand_reads(const DeviceBatch B) {
+    const int read = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (read >= B.num_reads) return;
+    const int lane = threadIdx.x & 63;
+    const int ro = B.read_off[read];
+    const int R = B.read_off[read + 1] - ro;
+    RowConst* dst = B.row_consts + ro + 2 * static_cast<int64_t>(read);
+    for (int i = lane; i <= R + 1; i += kWave) {
+        RowConst c{0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, kNoBase, 0u};
+        double t2 = 0.0, t4 = 1.0;  // a pad row hands its deletion mass down unweighted
+        if (i >= 1 && i <= R) {
+            const unsigned x = B.read_bases[ro + i - 1];
+            const double e = B.err_prob[B.read_quals[ro + i - 1]];
+            const unsigned ins = B.ins_gop[ro + i - 1] & 127u, del = B.del_gop[ro + i - 1] & 127u;
+            const double t0 = B.match_to_match[ins * 128u + del];
+            const double p = 1.0 - e;
+            const double q = (x == 'N') ? p : e / 3.0;  // a read 'N' matches every base
+            t2 = B.err_prob[ins];
+            t4 = B.err_prob[del];
+            c.p_match = static_cast<float>(p * t0);
+            c.p_mismatch = static_cast<float>(q * t0);
+            c.t5 = static_cast<float>(B.err_prob[B.gcp[ro + i - 1]]);
+            c.base = x;
+        }
+        if (i < R) {  // transitions of read row i + 1, taken from quals[i]
+            const unsigned ins = B.ins_gop[ro + i] & 127u, del = B.del_gop[ro + i] & 127u;
+            const double eg = B.err_prob[B.gcp[ro + i]];
+            const double t0n = B.match_to_match[ins * 128u + del];
+            const double t1n = 1.0 - eg;
+            if (i >= 1) {
+                c.c_f = static_cast<float>(t2 * eg / B.err_prob[ins]);
+                c.c_i = static_cast<float>(t2 * t1n / t0n);
+            }
+            c.c_e = static_cast<float>(t4 * t1n / t0n);
+        } else if (i == R) {
+            c.c_i = static_cast<float>(t2);  // last row: Sn = M + F * t2 = M + I, what the sum row adds up
+        } else {
+            c.p_match = c.p_mismatch = 1.0f;  // sum row
+        }
+        dst[i] = c;
     }
 }
 
@@ -536,6 +634,12 @@ hipError_t launch_fill_neg_inf(double* out, const int32_t* idx, int n, hipStream
     return hipGetLastError();
 }
 
+hipError_t launch_expand_reads(const DeviceBatch& B, hipStream_t stream) {
+    if (B.num_reads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(expand_reads, dim3((B.num_reads + 3) / 4), dim3(256), 0, stream, B);
+    return hipGetLastError();
+}
+
 hipError_t launch_validate(const DeviceBatch& B, hipStream_t stream) {
     if (B.total_read_bytes <= 0) return hipSuccess;
     int64_t blocks = (B.total_read_bytes + 255) / 256;
@@ -545,3 +649,14 @@ hipError_t launch_validate(const DeviceBatch& B, hipStream_t stream) {
 }
 
 }  // namespace pairhmm_hip
+
+#ifdef PAIRHMM_PHASE_CLOCKS
+extern "C" int gatk_pairhmm_debug_phase_clocks(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(pairhmm_hip::g_phase_clocks), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        const unsigned long long zero[8] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(pairhmm_hip::g_phase_clocks), zero, sizeof(zero));
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif

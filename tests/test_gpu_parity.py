@@ -135,7 +135,7 @@ def test_shapes_at_the_edges(hmm, oracle):
         pack([(seq(200), [25] * 200, None, None, None)], [seq(3)]),               # haplotype shorter than read
         pack([(seq(64), [30] * 64, None, None, None), (seq(65), [30] * 65, None, None, None)], [seq(90)]),  # 64 / 65 rows
         pack([(seq(511), rng.integers(10, 40, 511), None, None, None)], [seq(600), seq(513)]),  # 8 rows per lane
-        pack([(seq(1023), rng.integers(10, 40, 1023), None, None, None)], [seq(1100), seq(700)]),  # longest read
+        pack([(seq(1022), rng.integers(10, 40, 1022), None, None, None)], [seq(1100), seq(700)]),  # longest read
         pack([(seq(33), [30] * 33, None, None, None)] * 70, [seq(50)] * 3),       # many equal reads: several groups
     ]
     for b in cases:
@@ -172,7 +172,7 @@ def test_error_conventions(hmm):
     with pytest.raises(pairhmm.IllegalArgumentException):  # zero-length haplotype: undefined in the reference
         hmm.compute_batch(pack([ok], ["ACGT", ""]))
     with pytest.raises(pairhmm.IllegalArgumentException):  # read longer than the engine's maximum
-        hmm.compute_batch(pack([("A" * 1024, [30] * 1024, None, None, None)], ["ACGT"]))
+        hmm.compute_batch(pack([("A" * 1023, [30] * 1023, None, None, None)], ["ACGT"]))
     with pytest.raises(pairhmm.IllegalArgumentException):
         hmm.initialize(0, 10)
     with pytest.raises(pairhmm.IllegalArgumentException):
