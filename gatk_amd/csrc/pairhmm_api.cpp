@@ -23,6 +23,10 @@ namespace pairhmm_hip {
 hipError_t launch_forward(const DeviceBatch& B, int rows_per_lane, int emit_mode, bool fp64, bool list_mode,
                           int blocks, hipStream_t stream);
 int lds_bytes_per_wave(int rows_per_lane, int emit_mode, int max_hap_len);
+int stream_lds_bytes_per_wave(int rows_per_lane, int emit_mode);
+hipError_t launch_stream(const DeviceBatch& B, int rows_per_lane, int emit_mode, hipStream_t stream);
+hipError_t launch_expand_haps(const DeviceBatch& B, hipStream_t stream);
+hipError_t launch_finish_stream(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_validate(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_expand_reads(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_fill_neg_inf(double* out, const int32_t* idx, int n, hipStream_t stream);
@@ -102,6 +106,9 @@ struct Bucket {
     int max_hap_len = 0;
     int emit_mode = kEmitCompare;       // fp32 pass
     int emit_mode_fp64 = kEmitCompare;  // fp64 pass: always compares bytes
+    // fp32 stream pass (table modes only): haplotype runs instead of single haplotypes
+    bool stream = false;
+    int stream_desc_begin = 0, num_stream_descs = 0, num_stream_tasks = 0;
 };
 
 }  // namespace
@@ -122,11 +129,14 @@ struct gatk_pairhmm_resident {
     DevBuf d_arena;  // every input array of the call, one H2D copy
     DevBuf d_out, d_rerun_lists, d_counters;
     DevBuf d_row_consts;  // fp32 row constants of every read, written on the device
+    DevBuf d_hap_stream, d_raw_out, d_rerun_flags;  // fp32 stream pass
+    size_t hap_stream_entries = 0;
+    bool any_stream = false;
     DeviceBatch base{};  // pointers into d_arena
     const int32_t* d_neg_inf_idx = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     void release() {
-        for (DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_counters, &d_row_consts}) b->release();
+        for (DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_counters, &d_row_consts, &d_hap_stream, &d_raw_out, &d_rerun_flags}) b->release();
         for (auto& e : ev)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
     }
@@ -135,6 +145,7 @@ struct gatk_pairhmm_resident {
 struct gatk_pairhmm {
     int device = 0;
     hipStream_t stream = nullptr;
+    int wave_slots = 3072;  // waves the device holds at once at three per SIMD
     double* d_err = nullptr;
     double* d_mm = nullptr;
     bool initialized = false;
@@ -142,6 +153,8 @@ struct gatk_pairhmm {
     float fp32_threshold = 1e-28f;
     int force_rows_per_lane = 0;
     int emit_mode = -1;  // -1: table when the haplotype alphabet allows it; 0: always compare bytes
+    int stream_mode = -1;  // -1: haplotype runs in table modes; 0: one haplotype per work item
+    int max_stream_haps = kMaxStreamHaps;
     bool force_fp64 = false;
     bool timing = false;
     gatk_pairhmm_resident scratch;  // buffers reused by the host-pointer entry points
@@ -255,6 +268,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     R->num_regions = num_regions;
     R->region_out_off.assign(num_regions + 1, 0);
     R->buckets.clear(); R->descs.clear(); R->group_segs.clear();
+    R->any_stream = false;
     R->computed = false;
 
     // ---- pass 1: sizes, rows per lane, wave-groups ------------------------------------------------
@@ -280,6 +294,8 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     segs.reserve(static_cast<size_t>(total_reads));
     std::vector<int32_t> neg_inf_idx;
     std::vector<int> order;
+    std::vector<ReadInfo> read_info(static_cast<size_t>(total_reads), ReadInfo{0, 0, 0, -1});
+    std::vector<StreamDesc> stream_descs;
     bool any_hap_n = false, any_hap_other = false;
     int64_t cells = 0;
     int read_max_all = 0, hap_max_all = 0;
@@ -334,6 +350,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
                 const int seg = (len + 1 + K) / K;  // rows >= len + 2: a pad row in front, the sum row behind
                 if (used + seg > kWave) break;
                 segs.push_back(SegDesc{rp.read_begin + r, static_cast<uint8_t>(used), static_cast<uint8_t>(seg), static_cast<uint16_t>(len)});
+                read_info[rp.read_begin + r].task_base = static_cast<int32_t>(groups.size()) - rp.group_begin;  // group within the region, for now
                 used += seg;
                 max_seg = std::max(max_seg, seg);
                 ++g.num_segs; ++pos;
@@ -371,6 +388,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         bk.task_begin = static_cast<int>(total_tasks);
         bk.desc_begin = static_cast<int>(R->descs.size());
         int64_t t = 0;
+        const size_t bucket_first = i;
         for (; i < by_cost.size() && plans[by_cost[i]].K == K; ++i) {
             const RegionPlan& rp = plans[by_cost[i]];
             RegionDesc d{};
@@ -392,6 +410,51 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             const int lut = any_hap_n ? kEmitLut5 : kEmitLut4;
             // the table must leave room for at least one workgroup per CU (64 KiB dynamic LDS per block)
             if (lds_bytes_per_wave(K, lut, bk.max_hap_len) * kWavesPerBlock <= 64 * 1024) bk.emit_mode = lut;
+        }
+        // fp32 stream pass: the haplotype axis of every region is cut into runs; a run is as long as
+        // keeps every wave slot of the device supplied twice over, so runs shrink towards the end of
+        // the launch and the last waves to finish are short ones
+        bk.stream = (bk.emit_mode == kEmitLut4 || bk.emit_mode == kEmitLut5) && h->stream_mode != 0;
+        const int bucket_index = static_cast<int>(R->buckets.size());
+        if (bucket_index >= kMaxBuckets) return fail(GATK_PAIRHMM_ILLEGAL_STATE, "more launch buckets than rows-per-lane choices");
+        if (bk.stream) {
+            bk.stream_desc_begin = static_cast<int>(stream_descs.size());
+            int64_t remaining = t, st = 0;
+            for (size_t j = bucket_first; j < i; ++j) {
+                const RegionPlan& rp = plans[by_cost[j]];
+                for (int a = 0; a < rp.nh;) {
+                    int64_t c = remaining / (2 * static_cast<int64_t>(h->wave_slots));
+                    c = std::max<int64_t>(1, std::min<int64_t>(c, std::min(h->max_stream_haps, kMaxStreamHaps)));
+                    c = std::min<int64_t>(c, rp.nh - a);
+                    StreamDesc d{};
+                    d.task_begin = static_cast<int32_t>(st);
+                    d.group_begin = rp.group_begin;
+                    d.num_groups = rp.num_groups;
+                    d.hap_begin = rp.hap_begin + a;
+                    d.num_haps = static_cast<int32_t>(c);
+                    d.hap_local_begin = a;
+                    stream_descs.push_back(d);
+                    st += rp.num_groups;
+                    remaining -= static_cast<int64_t>(rp.num_groups) * c;
+                    a += static_cast<int>(c);
+                }
+            }
+            bk.num_stream_descs = static_cast<int>(stream_descs.size()) - bk.stream_desc_begin;
+            bk.num_stream_tasks = static_cast<int>(st);
+            R->any_stream = true;
+        }
+        for (size_t j = bucket_first; j < i; ++j) {
+            const RegionPlan& rp = plans[by_cost[j]];
+            const RegionDesc& d = R->descs[bk.desc_begin + (j - bucket_first)];
+            for (int r = 0; r < rp.nr; ++r) {
+                ReadInfo& ri = read_info[rp.read_begin + r];
+                const gatk_pairhmm_batch& b = regions[rp.region];
+                if (b.read_offsets[r + 1] == b.read_offsets[r] || !bk.stream) continue;  // zero-length reads have no work item
+                ri.task_base += d.task_begin;
+                ri.num_groups = rp.num_groups;
+                ri.num_haps = rp.nh;
+                ri.bucket = bucket_index;
+            }
         }
         total_tasks += t;
         R->buckets.push_back(bk);
@@ -416,6 +479,9 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     const size_t o_segs = L.add((segs.size() + 1) * sizeof(SegDesc));
     const size_t o_descs = L.add((R->descs.size() + 1) * sizeof(RegionDesc));
     const size_t o_neg = L.add((neg_inf_idx.size() + 1) * sizeof(int32_t));
+    const size_t o_hsoff = L.add((total_haps + 1) * sizeof(int32_t));
+    const size_t o_sdescs = L.add((stream_descs.size() + 1) * sizeof(StreamDesc));
+    const size_t o_rinfo = L.add((total_reads + 1) * sizeof(ReadInfo));
 
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(h->stage_in.ensure(L.size));
@@ -424,6 +490,8 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     int32_t* rout = reinterpret_cast<int32_t*>(S + o_rout);
     int32_t* hoff = reinterpret_cast<int32_t*>(S + o_hoff);
     int32_t* hlen = reinterpret_cast<int32_t*>(S + o_hlen);
+    int32_t* hsoff = reinterpret_cast<int32_t*>(S + o_hsoff);
+    size_t scur = kStreamFrontPad;  // haplotype stream: [pad] then per region  gap hap gap hap ... gap
     size_t rcur = 0, hcur = 0;
     int ri = 0, hi = 0;
     roff[0] = 0;
@@ -443,8 +511,11 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             roff[++ri] = static_cast<int32_t>(rcur + (b.read_offsets[r + 1] - bo));
         }
         rcur += total;
+        ++scur;  // the region's first gap
         for (int a = 0; a < nh; ++a) {
             const int o = b.hap_offsets[a], len = b.hap_offsets[a + 1] - o;
+            hsoff[hi] = static_cast<int32_t>(scur);
+            scur += static_cast<size_t>(len) + 1;
             hoff[hi] = static_cast<int32_t>(hcur);
             hlen[hi++] = len;
             memcpy(S + o_hpool + hcur, b.hap_bases + o, len);
@@ -458,6 +529,10 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     if (!segs.empty()) memcpy(S + o_segs, segs.data(), segs.size() * sizeof(SegDesc));
     if (!R->descs.empty()) memcpy(S + o_descs, R->descs.data(), R->descs.size() * sizeof(RegionDesc));
     if (!neg_inf_idx.empty()) memcpy(S + o_neg, neg_inf_idx.data(), neg_inf_idx.size() * sizeof(int32_t));
+    if (!stream_descs.empty()) memcpy(S + o_sdescs, stream_descs.data(), stream_descs.size() * sizeof(StreamDesc));
+    if (!read_info.empty()) memcpy(S + o_rinfo, read_info.data(), read_info.size() * sizeof(ReadInfo));
+    R->hap_stream_entries = scur + kStreamBackPad;
+    if (R->hap_stream_entries >= (size_t{1} << 31)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "more than 2^31 haplotype bases in one call");
     const double t_planned = now_ms();
 
     hipStream_t s = h->stream;
@@ -466,6 +541,11 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     HIP_TRY(R->d_rerun_lists.ensure(std::max<size_t>(static_cast<size_t>(total_tasks) * sizeof(int32_t), 16)));
     HIP_TRY(R->d_counters.ensure(256));
     HIP_TRY(R->d_row_consts.ensure((rbytes + 2 * static_cast<size_t>(total_reads) + 2) * sizeof(RowConst)));
+    if (R->any_stream) {
+        HIP_TRY(R->d_hap_stream.ensure(R->hap_stream_entries * sizeof(uint16_t)));
+        HIP_TRY(R->d_raw_out.ensure(std::max<size_t>(static_cast<size_t>(call_pairs) * sizeof(float), 16)));
+        HIP_TRY(R->d_rerun_flags.ensure(std::max<size_t>(static_cast<size_t>(total_tasks) * sizeof(int32_t), 16)));
+    }
     if (L.size) HIP_TRY(hipMemcpyAsync(R->d_arena.p, S, L.size, hipMemcpyHostToDevice, s));
     const uint8_t* D = R->d_arena.as<uint8_t>();
     DeviceBatch& B = R->base;
@@ -481,6 +561,14 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     B.region_descs = reinterpret_cast<const RegionDesc*>(D + o_descs);
     B.total_read_bytes = total_read_bytes;
     B.num_reads = static_cast<int32_t>(total_reads);
+    B.num_haps = static_cast<int32_t>(total_haps);
+    B.hap_stream_off = reinterpret_cast<const int32_t*>(D + o_hsoff);
+    B.stream_descs = reinterpret_cast<const StreamDesc*>(D + o_sdescs);
+    B.read_info = reinterpret_cast<const ReadInfo*>(D + o_rinfo);
+    B.hap_stream = R->d_hap_stream.as<uint16_t>();
+    B.raw_out = R->d_raw_out.as<float>();
+    B.rerun_flags = R->d_rerun_flags.as<int32_t>();
+    for (size_t bi = 0; bi < R->buckets.size(); ++bi) B.bucket_task_begin[bi] = R->buckets[bi].task_begin;
     B.row_consts = R->d_row_consts.as<RowConst>();
     R->d_neg_inf_idx = reinterpret_cast<const int32_t*>(D + o_neg);
     // the staging buffer is reused by the next upload on this handle: finish the copy first
@@ -491,7 +579,6 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
 }
 
 // counters layout: [0] error word, [1 + b] rerun count of bucket b
-constexpr int kMaxBuckets = 16;  // one bucket per rows-per-lane value in use
 
 int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     HIP_TRY(hipSetDevice(h->device));
@@ -508,7 +595,15 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     B.error_word = R->d_counters.as<int32_t>();
     B.fp32_threshold = h->fp32_threshold;
     HIP_TRY(launch_validate(B, s));
+    B.rerun_counts = R->d_counters.as<int32_t>() + 1;
+    B.rerun_lists = R->d_rerun_lists.as<int32_t>();
+    const bool streaming = R->any_stream && !h->force_fp64;
     if (!h->force_fp64) HIP_TRY(launch_expand_reads(B, s));
+    if (streaming) {
+        HIP_TRY(hipMemsetAsync(B.hap_stream, 0, R->hap_stream_entries * sizeof(uint16_t), s));
+        HIP_TRY(hipMemsetAsync(B.rerun_flags, 0, std::max<size_t>(static_cast<size_t>(R->total_tasks) * sizeof(int32_t), 16), s));
+        HIP_TRY(launch_expand_haps(B, s));
+    }
     if (R->num_neg_inf > 0) HIP_TRY(launch_fill_neg_inf(B.out, R->d_neg_inf_idx, R->num_neg_inf, s));
     if (timing) HIP_TRY(hipEventRecord(R->ev[0], s));
     auto bucket_args = [&](size_t bi, int mode) {
@@ -525,9 +620,19 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     for (size_t bi = 0; bi < R->buckets.size(); ++bi) {
         const Bucket& bk = R->buckets[bi];
         const int mode = h->force_fp64 ? bk.emit_mode_fp64 : bk.emit_mode;
+        if (streaming && bk.stream) {
+            DeviceBatch L = bucket_args(bi, mode);
+            L.stream_descs = B.stream_descs + bk.stream_desc_begin;
+            L.num_stream_descs = bk.num_stream_descs;
+            L.num_tasks = bk.num_stream_tasks;
+            L.lds_per_wave = stream_lds_bytes_per_wave(bk.rows_per_lane, mode);
+            HIP_TRY(launch_stream(L, bk.rows_per_lane, mode, s));
+            continue;
+        }
         const int blocks = (bk.num_tasks + kWavesPerBlock - 1) / kWavesPerBlock;
         HIP_TRY(launch_forward(bucket_args(bi, mode), bk.rows_per_lane, mode, h->force_fp64, false, blocks, s));
     }
+    if (streaming) HIP_TRY(launch_finish_stream(B, s));
     if (timing) HIP_TRY(hipEventRecord(R->ev[1], s));
     if (!h->force_fp64) {
         for (size_t bi = 0; bi < R->buckets.size(); ++bi) {
@@ -650,6 +755,9 @@ int gatk_pairhmm_create(int device, gatk_pairhmm** out) {
     gatk_pairhmm* h = new gatk_pairhmm();
     h->device = device;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    int cus = 0;
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (cus > 0) h->wave_slots = cus * 12;
     const Tables& t = tables();
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_err), sizeof t.err_prob);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_mm), t.match_to_match.size() * sizeof(double));
@@ -847,6 +955,8 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
     else if (n == "force_fp64") h->force_fp64 = value != 0;
     else if (n == "emit_mode") h->emit_mode = static_cast<int>(value);
     else if (n == "timing") h->timing = value != 0;
+    else if (n == "stream_mode") h->stream_mode = static_cast<int>(value);
+    else if (n == "max_stream_haps") h->max_stream_haps = std::max(1, static_cast<int>(value));
     else return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "unknown option " + n);
     return GATK_PAIRHMM_OK;
 }

@@ -73,6 +73,32 @@ struct RegionDesc {
     int32_t reserved[3];
 };
 
+// Work items of the fp32 stream pass: item t in [task_begin, task_begin + num_groups) sweeps wave-group
+// group_begin + (t - task_begin) over haplotypes [hap_begin, hap_begin + num_haps) back to back.
+// hap_local_begin: index of hap_begin among its region's haplotypes.  Sorted by task_begin.
+constexpr int kMaxStreamHaps = 16;
+struct StreamDesc {
+    int32_t task_begin;
+    int32_t group_begin;
+    int32_t num_groups;
+    int32_t hap_begin;
+    int32_t num_haps;
+    int32_t hap_local_begin;
+    int32_t reserved[2];
+};
+
+// What the pass that turns the stream pass's raw sums into log10 needs to know about a read.
+struct ReadInfo {
+    int32_t task_base;   // single-haplotype work item of (this read's wave-group, haplotype 0), bucket-local
+    int32_t num_groups;  // wave-groups of the read's region: the item of haplotype a is task_base + a * num_groups
+    int32_t num_haps;    // haplotypes of the read's region; 0: nothing to do for this read
+    int32_t bucket;      // launch bucket of the region, or -1 when the stream pass did not score it
+};
+
+constexpr int kMaxBuckets = 16;  // one bucket per rows-per-lane value in use
+constexpr int kStreamFrontPad = 64;  // entries in front of the haplotype stream: lanes ahead of the first column read here
+constexpr int kStreamBackPad = 128;  // entries behind it: draining lanes and the read-ahead land here
+
 // Kernel arguments.  All pointers are device pointers.
 struct DeviceBatch {
     const uint8_t* read_bases;
@@ -90,6 +116,18 @@ struct DeviceBatch {
     const RegionDesc* region_descs;  // this launch's regions
     RowConst* row_consts;          // [total_read_bytes + 2 * num_reads], written by the expansion kernel
     int32_t num_reads;
+    int32_t num_haps;
+    // fp32 stream pass
+    uint16_t* hap_stream;          // table offsets (base code * 512) of every haplotype, one zero entry between neighbours
+    const int32_t* hap_stream_off; // [num_haps] index of a haplotype's first base in hap_stream
+    const StreamDesc* stream_descs;
+    int32_t num_stream_descs;
+    float* raw_out;                // [pairs] scaled likelihood sums, laid out like out
+    const ReadInfo* read_info;     // [num_reads]
+    int32_t* rerun_flags;          // [work items of all buckets] 1 once an item is on a rerun list
+    int32_t* rerun_counts;         // [kMaxBuckets]
+    int32_t* rerun_lists;          // rerun lists of all buckets, bucket b starting at bucket_task_begin[b]
+    int32_t bucket_task_begin[kMaxBuckets];
     int32_t num_region_descs;
     int32_t num_tasks;             // this launch's work items
     const double* err_prob;        // [256]

@@ -471,6 +471,291 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 stream pass
+// ---------------------------------------------------------------------------------------------
+// A wave keeps its wave-group (row constants in registers, emission table in LDS) and sweeps a run of
+// haplotypes back to back.  The region's haplotypes lie in hap_stream as
+//     gap hap0 gap hap1 gap ... gap            (gap: one entry)
+// and the sweep treats the run as one long haplotype: at step s the lane at segment position t is at
+// stream position s - t.  A gap is column 0 of the haplotype behind it and the end of the one in front
+// of it: a lane arriving there hands in the finished haplotype's sum (segment-last lanes) and
+// re-initialises its rows; everywhere else it computes a column.  So the pipeline fills and drains
+// once per run instead of once per haplotype, and nothing per read is redone between haplotypes.
+//
+// Steps are taken four at a time.  A block of four steps in which no lane is at a gap runs the
+// unmasked column code; a block that has some lane at a gap takes the masked path.  Haplotype codes
+// come straight from global memory, kStreamAhead blocks ahead of their use.
+constexpr int kStreamAhead = 4;
+
+struct StreamLane {
+    int next_gap;  // stream position (relative to the run's first gap) of the next gap this lane meets
+    int gap_idx;   // its index: gap c is column 0 of haplotype c
+    float init_d;  // scale / H of the haplotype behind that gap
+};
+
+__device__ __forceinline__ uint2 load_codes(const uint16_t* p) {
+    uint2 v;
+    __builtin_memcpy(&v, p, sizeof v);  // 2-byte aligned
+    return v;
+}
+
+template <int K, int MODE>
+__device__ __forceinline__ void run_stream(const DeviceBatch& B, const int task_idx, unsigned char* slice, const int lane) {
+    using T = float;
+    constexpr int kCodes = lut_codes(MODE);
+    static_assert(is_lut(MODE), "the stream pass reads emission terms from the table");
+    PHASE_BEGIN();
+    // ---- which wave-group and haplotype run? (wave-uniform) ------------------------------------------
+    int lo = 0, hi = B.num_stream_descs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (B.stream_descs[mid].task_begin <= task_idx) lo = mid; else hi = mid - 1;
+    }
+    const StreamDesc sdesc = B.stream_descs[lo];
+    const GroupDesc grp = B.groups[sdesc.group_begin + (task_idx - sdesc.task_begin)];
+    const int fill = grp.fill;
+    const int C = sdesc.num_haps;
+    LaneInfo ld{-1, 1, 0, 0};
+    int R = 0;
+    for (int k = 0; k < grp.num_segs; ++k) {
+        const SegDesc sd = B.segs[grp.seg_begin + k];
+        const int t = lane - static_cast<int>(sd.lane_begin);
+        if (t >= 0 && t < static_cast<int>(sd.seg_lanes)) {
+            R = sd.read_len;
+            ld.read_idx = sd.read_idx;
+            ld.seg_lane = t;
+            ld.first_row = t * K + 1 - (static_cast<int>(sd.seg_lanes) * K - R - 1);  // pads | rows 1..R | sum row
+            ld.seg_last = (t == static_cast<int>(sd.seg_lanes) - 1) ? 1 : 0;
+        }
+    }
+    const bool used = ld.read_idx >= 0;
+    // ---- the run's gaps -> LDS: {position relative to the first gap, scale / H of the haplotype behind it}
+    int2* const gaps = reinterpret_cast<int2*>(slice + lut_table_bytes(K, MODE));
+    const int run_base = B.hap_stream_off[sdesc.hap_begin] - 1;  // the run's first gap
+    if (lane <= C + 1) {
+        const int a = sdesc.hap_begin + (lane < C ? lane : C - 1);
+        const int off = B.hap_stream_off[a], len = B.hap_len[a];
+        int2 g;
+        g.x = lane < C ? off - 1 - run_base : lane == C ? off + len - run_base : 0x7fffffff;
+        g.y = __float_as_int(static_cast<float>(::ldexp(1.0, Scale<T>::kExp2) / static_cast<double>(len)));
+        gaps[lane] = g;
+    }
+    PHASE_END(0);
+    // ---- per-row constants and the emission table -------------------------------------------------------
+    Rows<T, K> w;
+    int out_base = 0;
+    {
+        int ro = 0;
+        if (used) {
+            ro = B.read_off[ld.read_idx];
+            out_base = B.read_out_base[ld.read_idx] + sdesc.hap_local_begin;
+        }
+        const int rc_base = ro + 2 * (used ? ld.read_idx : 0);
+        float4 c0[K], c1[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            int e = ld.first_row + r;
+            e = e < 0 ? 0 : (e > R + 1 ? R + 1 : e);
+            const float4* src = reinterpret_cast<const float4*>(B.row_consts + rc_base + e);
+            c0[r] = src[0];
+            c1[r] = src[1];
+        }
+        float* tbl = reinterpret_cast<float*>(slice);
+        const unsigned letters[5] = {'A', 'C', 'T', 'G', 'N'};
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const bool deep_pad = ld.first_row + r < 0;  // the row below is a pad row too: hand down anything finite
+            const float P = (used && !deep_pad) ? c0[r].x : 0.0f;
+            const float Q = (used && !deep_pad) ? c0[r].y : 0.0f;
+            const unsigned xb = (used && !deep_pad) ? __float_as_uint(c1[r].z) : kNoBase;
+            w.T5[r] = !used ? 0.0f : deep_pad ? 1.0f : c0[r].z;
+            w.A[r] = (used && !deep_pad) ? c0[r].w : 0.0f;
+            w.B[r] = (used && !deep_pad) ? c1[r].x : 0.0f;
+            w.C[r] = !used ? 0.0f : deep_pad ? 1.0f : c1[r].y;
+            pin(w.A[r]); pin(w.B[r]); pin(w.C[r]); pin(w.T5[r]);
+            w.Ml[r] = 0.0f; w.El[r] = 0.0f; w.Sd[r] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < kCodes; ++c)
+                tbl[(((r >> 1) * kCodes + c) * kWave + lane) * 2 + (r & 1)] = (xb == letters[c] || c == 4) ? P : Q;
+        }
+        w.Sout = 0.0f; w.Iout = 0.0f;
+    }
+    // pad rows of this lane: rows [0, num_pad)
+    const int num_pad = used ? (1 - ld.first_row < 0 ? 0 : (1 - ld.first_row > K ? K : 1 - ld.first_row)) : 0;
+    __builtin_amdgcn_wave_barrier();
+    const int run_end = __builtin_amdgcn_readfirstlane(gaps[C].x);  // the gap behind the last haplotype
+    PHASE_END(1);
+
+    // ---- sweep -----------------------------------------------------------------------------------------
+    const int t = ld.seg_lane;
+    const uint16_t* const hp = B.hap_stream + run_base - t;  // hp[s]: table offset of this lane's position at step s
+    const unsigned char* const tbl_lane = slice + lane * 8;
+    auto emit = [&](const unsigned code_off, T (&prior)[K]) {
+#pragma unroll
+        for (int g = 0; g < lut_row_pairs(K); ++g) {
+            const float2 v = *reinterpret_cast<const float2*>(tbl_lane + code_off + g * kCodes * kLutCodeStride);
+            prior[2 * g] = v.x;
+            if (2 * g + 1 < K) prior[2 * g + 1] = v.y;
+        }
+    };
+    auto emit4 = [&](const uint2 codes, T (&prior)[4][K]) {
+        emit(codes.x & 0xffffu, prior[0]);
+        emit(codes.x >> 16, prior[1]);
+        emit(codes.y & 0xffffu, prior[2]);
+        emit(codes.y >> 16, prior[3]);
+    };
+    StreamLane sl{0, 0, __int_as_float(gaps[0].y)};
+    // One step of a block in which some lane is at a gap.  A lane at a gap hands in the finished
+    // haplotype's sum, then clears M, E and the diagonal terms (pad rows: E = scale / H) and takes
+    // no insertion mass from above: the column it computes next is then exactly column 0 of the
+    // next haplotype (M = I = 0, D as initialised, hand-offs to the right and downwards included),
+    // whatever base code the gap entry holds.  Lanes outside the run compute on, unobserved.
+    auto masked_step = [&](const int step, const unsigned code_off) {
+        const T Sin = shr1(w.Sout);
+        T Iin = shr1(w.Iout);
+        if (step - t == sl.next_gap) {
+            if (sl.gap_idx > 0 && ld.seg_last != 0 && used)
+                B.raw_out[out_base + sl.gap_idx - 1] = w.El[K - 1] + w.Ml[K - 1] + w.Sd[K - 1];  // the sum row
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                w.Ml[r] = 0.0f;
+                w.El[r] = r < num_pad ? sl.init_d : 0.0f;
+                w.Sd[r] = 0.0f;
+            }
+            Iin = 0.0f;
+            const int2 next = gaps[sl.gap_idx + 1];
+            sl.next_gap = next.x;
+            sl.init_d = __int_as_float(next.y);
+            ++sl.gap_idx;
+        }
+        T prior[K];
+        emit(code_off, prior);
+        column<T, K>(w, prior, Sin, Iin);
+    };
+
+    const int num_blocks = (run_end + fill + 4) >> 2;  // steps 0 .. run_end + fill
+    // codes: table offsets of block q; ahead[d]: those of block q + 1 + d, on their way from global memory
+    uint2 codes = load_codes(hp);
+    uint2 ahead[kStreamAhead];
+#pragma unroll
+    for (int d = 0; d < kStreamAhead; ++d) ahead[d] = load_codes(hp + 4 * (d + 1));
+    auto advance_codes = [&](const int q) {
+        codes = ahead[0];
+#pragma unroll
+        for (int d = 0; d + 1 < kStreamAhead; ++d) ahead[d] = ahead[d + 1];
+        ahead[kStreamAhead - 1] = load_codes(hp + 4 * (q + kStreamAhead + 1));
+    };
+    int gap_s = 0;       // wave-uniform: index of the first gap that some lane has still to pass
+    int gap_pos_s = 0;   // and its position
+    int q = 0;
+    while (q < num_blocks) {
+        const int s0 = q << 2;
+        while (s0 - fill > gap_pos_s) {  // every lane is past that gap
+            ++gap_s;
+            gap_pos_s = __builtin_amdgcn_readfirstlane(gaps[gap_s].x);
+        }
+        // blocks from here on in which no lane meets a gap: s0' + 3 < gap_pos_s
+        const int steady = s0 + 3 < gap_pos_s ? (gap_pos_s - s0) >> 2 : 0;
+        if (steady > 0) {
+            // two-deep software pipeline: emission terms of the next block are in flight while the
+            // current block is computed
+            T pc[4][K];
+            emit4(codes, pc);
+            for (const int q_end = q + steady; q < q_end; ++q) {
+                T pn[4][K];
+                advance_codes(q);
+                emit4(codes, pn);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const T Sin = shr1(w.Sout);
+                    const T Iin = shr1(w.Iout);
+                    column<T, K>(w, pc[u], Sin, Iin);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < K; ++r) pc[u][r] = pn[u][r];
+            }
+        } else {
+            masked_step(s0, codes.x & 0xffffu);
+            masked_step(s0 + 1, codes.x >> 16);
+            masked_step(s0 + 2, codes.y & 0xffffu);
+            masked_step(s0 + 3, codes.y >> 16);
+            advance_codes(q);
+            ++q;
+        }
+    }
+    PHASE_END(3);
+}
+
+template <int K, int MODE>
+__global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_stream(const DeviceBatch B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int task = blockIdx.x * kWavesPerBlock + wave;
+    if (task >= B.num_tasks) return;
+#ifdef PAIRHMM_PHASE_CLOCKS
+    const long long life_c0 = clock64(), life_w0 = wall_clock64();
+#endif
+    run_stream<K, MODE>(B, task, lds + wave * B.lds_per_wave, lane);
+#ifdef PAIRHMM_PHASE_CLOCKS
+    if (lane == 0) {  // wave lifetime in shader-clock ticks and in ticks of the constant 100 MHz counter
+        atomicAdd(&g_phase_clocks[4], (unsigned long long)(clock64() - life_c0));
+        atomicAdd(&g_phase_clocks[7], (unsigned long long)(wall_clock64() - life_w0));
+        atomicAdd(&g_phase_clocks[6], 1ull);
+    }
+#endif
+}
+
+// Haplotype bytes -> table offsets in the stream (the gaps and pads were zeroed beforehand).
+__global__ void __launch_bounds__(256) expand_haps(const DeviceBatch B) {
+    const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= B.num_haps) return;
+    const uint8_t* src = B.hap_pool + B.hap_off[a];
+    uint16_t* dst = B.hap_stream + B.hap_stream_off[a];
+    const int len = B.hap_len[a];
+    for (int j = threadIdx.x & 63; j < len; j += kWave) {
+        const unsigned byte = src[j];
+        dst[j] = static_cast<uint16_t>((byte == 'N' ? 4u : ((byte >> 1) & 3u)) * kLutCodeStride);
+    }
+}
+
+// Raw sums of the stream pass -> log10 likelihoods; pairs fp32 could not hold go on their bucket's
+// rerun list as single-haplotype work items (once each, whichever of the group's reads asks first).
+__global__ void __launch_bounds__(256) finish_stream(const DeviceBatch B) {
+    const int read = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (read >= B.num_reads) return;
+    const ReadInfo info = B.read_info[read];
+    if (info.bucket < 0) return;
+    const int ob = B.read_out_base[read];
+    const int lane = threadIdx.x & 63;
+    const int list_begin = B.bucket_task_begin[info.bucket];
+    for (int a0 = 0; a0 < info.num_haps; a0 += kWave) {  // wave-uniform trip count
+        const int a = a0 + lane;
+        bool push = false;
+        int task = 0;
+        if (a < info.num_haps) {
+            const float total = B.raw_out[ob + a];
+            B.out[ob + a] = ::log10(static_cast<double>(total)) - Scale<float>::kExp2 * 0.30102999566398119521;
+            if (!(total >= B.fp32_threshold && total <= 3.0e38f)) {
+                task = info.task_base + a * info.num_groups;
+                push = atomicExch(&B.rerun_flags[list_begin + task], 1) == 0;
+            }
+        }
+        // one counter update per wave: the first pushing lane reserves room for all of them
+        const unsigned long long pushing = __ballot(push);
+        if (pushing != 0) {
+            const int leader = __ffsll(static_cast<long long>(pushing)) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&B.rerun_counts[info.bucket], __popcll(pushing));
+            base = __shfl(base, leader);
+            if (push) B.rerun_lists[list_begin + base + __popcll(pushing & ((1ull << lane) - 1ull))] = task;
+        }
+    }
+}
+
 // One task per wave, tasks taken in launch order.
 template <typename T, int K, int MODE>
 __global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_direct(const DeviceBatch B) {
@@ -609,7 +894,54 @@ hipError_t launch_t(const DeviceBatch& B, int K, int mode, bool list_mode, int b
     }
 }
 
+template <int K>
+hipError_t launch_stream_k(const DeviceBatch& B, int mode, int blocks, hipStream_t stream) {
+    const size_t lds = static_cast<size_t>(B.lds_per_wave) * kWavesPerBlock;
+    const dim3 grid(blocks), block(kWave * kWavesPerBlock);
+    if (mode == kEmitLut4) hipLaunchKernelGGL((fwd_stream<K, kEmitLut4>), grid, block, lds, stream, B);
+    else if (mode == kEmitLut5) hipLaunchKernelGGL((fwd_stream<K, kEmitLut5>), grid, block, lds, stream, B);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 }  // namespace
+
+// Bytes of LDS one wave of the stream pass needs: the emission table and the run's gap list.
+int stream_lds_bytes_per_wave(int rows_per_lane, int emit_mode) {
+    return (lut_table_bytes(rows_per_lane, emit_mode) + (kMaxStreamHaps + 2) * 8 + 15) & ~15;
+}
+
+// Enqueue the fp32 stream pass for one bucket (B.stream_descs / num_stream_descs / num_tasks set for it).
+hipError_t launch_stream(const DeviceBatch& B, int rows_per_lane, int emit_mode, hipStream_t stream) {
+    if (B.num_tasks <= 0) return hipSuccess;
+    const int blocks = (B.num_tasks + kWavesPerBlock - 1) / kWavesPerBlock;
+    switch (rows_per_lane) {
+        case 1: return launch_stream_k<1>(B, emit_mode, blocks, stream);
+        case 2: return launch_stream_k<2>(B, emit_mode, blocks, stream);
+        case 3: return launch_stream_k<3>(B, emit_mode, blocks, stream);
+        case 4: return launch_stream_k<4>(B, emit_mode, blocks, stream);
+        case 5: return launch_stream_k<5>(B, emit_mode, blocks, stream);
+        case 6: return launch_stream_k<6>(B, emit_mode, blocks, stream);
+        case 7: return launch_stream_k<7>(B, emit_mode, blocks, stream);
+        case 8: return launch_stream_k<8>(B, emit_mode, blocks, stream);
+        case 10: return launch_stream_k<10>(B, emit_mode, blocks, stream);
+        case 12: return launch_stream_k<12>(B, emit_mode, blocks, stream);
+        case 16: return launch_stream_k<16>(B, emit_mode, blocks, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_expand_haps(const DeviceBatch& B, hipStream_t stream) {
+    if (B.num_haps <= 0) return hipSuccess;
+    hipLaunchKernelGGL(expand_haps, dim3((B.num_haps + 3) / 4), dim3(256), 0, stream, B);
+    return hipGetLastError();
+}
+
+hipError_t launch_finish_stream(const DeviceBatch& B, hipStream_t stream) {
+    if (B.num_reads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(finish_stream, dim3((B.num_reads + 3) / 4), dim3(256), 0, stream, B);
+    return hipGetLastError();
+}
 
 // Bytes of LDS one wave needs for a launch with these parameters.
 int lds_bytes_per_wave(int rows_per_lane, int emit_mode, int max_hap_len) {

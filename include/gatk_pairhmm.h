@@ -139,7 +139,10 @@ int gatk_pairhmm_device_count(int32_t* count);
 /* Engine tunables (all optional).  name: "fp32_threshold" (default 1e-28: a pair whose scaled
  * fp32 sum falls below it is recomputed in fp64), "force_rows_per_lane" (0 = automatic),
  * "force_fp64" (1 = score everything in fp64), "emit_mode" (-1 = automatic, 0 = always compare bases
- * instead of using the per-wave emission table), "timing" (1 = fill the *_kernel_ms stats). */
+ * instead of using the per-wave emission table), "timing" (1 = fill the *_kernel_ms stats),
+ * "stream_mode" (-1 = automatic: a wave scores a run of haplotypes back to back; 0 = one haplotype per
+ * work item), "max_stream_haps" (longest run, 1..16).  Planning options take effect at the next
+ * upload or host-pointer call. */
 int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value);
 
 /*

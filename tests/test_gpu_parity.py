@@ -369,3 +369,77 @@ def test_extreme_gap_quality_steps(hmm, oracle):
         reads.append((hap[20 + k:20 + k + n], rng.integers(5, 41, n), ins, dele, rng.integers(1, 60, n)))
     b = pack(reads, [hap, hap[10:150]])
     assert_parity(hmm.compute_batch(b), ref(oracle, b, 1))
+
+
+# ---- haplotype runs (the fp32 stream pass) ------------------------------------------------------
+
+def with_options(hmm, opts, fn):
+    defaults = {"stream_mode": -1, "max_stream_haps": 16, "force_rows_per_lane": 0, "emit_mode": -1}
+    for k, v in opts.items():
+        hmm.set_option(k, v)
+    try:
+        return fn()
+    finally:
+        for k in opts:
+            hmm.set_option(k, defaults[k])
+
+
+@pytest.mark.parametrize("run", [1, 2, 3, 5, 16])
+def test_haplotype_runs_of_every_length(hmm, oracle, run):
+    # 23 haplotypes of ragged length: runs of `run` haplotypes plus a shorter last run
+    b = synth.make_batch(50, 23, 101, 300, seed=500 + run, len_jitter=40, hap_len_jitter=120, gop_model="random")
+    want = ref(oracle, b)
+    got = with_options(hmm, {"max_stream_haps": run}, lambda: hmm.compute_batch(b))
+    assert_parity(got, want)
+
+
+def test_runs_and_single_haplotype_items_agree(hmm, oracle):
+    b = synth.make_batch(300, 40, 151, 420, seed=77, len_jitter=30, hap_len_jitter=60)
+    runs = hmm.compute_batch(b)
+    single = with_options(hmm, {"stream_mode": 0}, lambda: hmm.compute_batch(b))
+    compare = with_options(hmm, {"emit_mode": 0}, lambda: hmm.compute_batch(b))
+    want = ref(oracle, b)
+    for got in (runs, single, compare):
+        assert_parity(got, want)
+    # the three fp32 passes evaluate the same expression tree cell by cell
+    np.testing.assert_allclose(runs, single, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(runs, compare, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 8, 10, 16])
+def test_runs_with_haplotypes_shorter_than_the_pipeline(hmm, oracle, k):
+    # haplotypes of 1..12 bases against reads of up to 60 bases: with few rows per lane a read spans more
+    # lanes than a haplotype has columns, so several gaps are inside the wave at once
+    rng = np.random.default_rng(k)
+    haps = ["".join(rng.choice(list("ACGT"), size=n)) for n in (1, 2, 3, 1, 12, 5, 7, 1, 1, 4, 9, 2, 6)]
+    src = synth.make_batch(30, 1, 60, 200, seed=900 + k, len_jitter=59)
+    b = Batch(src.read_bases, src.read_quals, src.ins_gop, src.del_gop, src.gcp, src.read_offsets,
+              np.frombuffer("".join(haps).encode(), dtype=np.uint8).copy(),
+              np.concatenate([[0], np.cumsum([len(h) for h in haps])]).astype(np.int32))
+    want = ref(oracle, b)
+    got = with_options(hmm, {"force_rows_per_lane": k}, lambda: hmm.compute_batch(b))
+    assert_parity(got, want)
+
+
+def test_runs_requeue_underflowing_pairs_once(hmm, oracle):
+    # half the haplotypes are unrelated to the reads: their pairs underflow fp32 and go through the
+    # fp64 pass as single-haplotype items, whichever run they were scored in
+    b = synth.config_c5(num_reads=96, num_haps=12)
+    want = ref(oracle, b)
+    got = hmm.compute_batch(b)
+    assert_parity(got, want)
+    st = hmm.stats()
+    assert 0 < st["rerun_pairs"] <= st["pairs"]
+    assert st["rerun_tasks"] <= st["wave_tasks"]
+
+
+def test_runs_across_regions_with_n_in_haplotypes(hmm, oracle):
+    regions = synth.make_regions(12, seed=5, coverage=10, read_len=120)
+    # an 'N' in one haplotype switches every launch of the call to the five-letter table
+    hb = regions[3].hap_bases.copy()
+    hb[7] = ord("N")
+    r3 = regions[3]
+    regions[3] = Batch(r3.read_bases, r3.read_quals, r3.ins_gop, r3.del_gop, r3.gcp, r3.read_offsets, hb, r3.hap_offsets)
+    outs = hmm.compute_regions(regions)
+    for b, o in zip(regions, outs):
+        assert_parity(o, ref(oracle, b))

@@ -172,6 +172,25 @@ __global__ void __launch_bounds__(256) k_rate(float* out, int iters, float a, fl
     out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
 }
 
+// Shader clock under a full fp32 load: s_memtime ticks against the constant 100 MHz counter.
+__global__ void __launch_bounds__(256) k_clock(float* out, long long* ticks, int iters, float a, float b) {
+    float x0 = threadIdx.x * 1e-3f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); x3 = __builtin_fmaf(x3, a, b);
+            x4 = __builtin_fmaf(x4, a, b); x5 = __builtin_fmaf(x5, a, b); x6 = __builtin_fmaf(x6, a, b); x7 = __builtin_fmaf(x7, a, b);
+        }
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+    if (threadIdx.x == 0 && (blockIdx.x % 97) == 0) {
+        ticks[2 * (blockIdx.x / 97)] = c1 - c0;
+        ticks[2 * (blockIdx.x / 97) + 1] = w1 - w0;
+    }
+}
+
 template <int MODE>
 static int run_rate(const char* name, double instr_per_iter, double flop_per_instr, float* d_out) {
     int dev_cus = 256;
@@ -206,6 +225,17 @@ int main() {
     int ok = (h[0] == -1.0f);
     for (int i = 1; i < 64; i++) ok &= (h[i] == (float)(i - 1));
     printf("dpp wave_shr:1 %s  (lane0=%g lane1=%g lane16=%g lane32=%g lane63=%g)\n", ok ? "OK" : "WRONG", h[0], h[1], h[16], h[32], h[63]);
+    {
+        long long* d_ticks; CK(hipMalloc(&d_ticks, sizeof(long long) * 64));
+        for (int wavesPerSimd = 1; wavesPerSimd <= 4; wavesPerSimd *= 2) {
+            const int blocks = 256 * wavesPerSimd, iters = 200000;
+            hipLaunchKernelGGL(k_clock, dim3(blocks), dim3(256), 0, 0, d_out, d_ticks, iters, 0.999f, 0.001f);
+            long long t[8]; CK(hipMemcpy(t, d_ticks, sizeof t, hipMemcpyDeviceToHost));
+            for (int k = 0; k < 2; k++)
+                printf("clock under fp32 load, waves/SIMD=%d: s_memtime %lld ticks, 100MHz counter %lld ticks -> %.0f MHz if s_memtime counts shader cycles; %.2f ticks per wave-instr\n",
+                       wavesPerSimd, t[2 * k], t[2 * k + 1], 100.0 * t[2 * k] / t[2 * k + 1], (double)t[2 * k] / (iters * 64.0 * wavesPerSimd));
+        }
+    }
     if (run_rate<0>("v_fma_f32 x8 indep", 64, 2, d_out)) return 1;
     if (run_rate<1>("v_pk_fma_f32 x4 indep", 32, 4, d_out)) return 1;
     if (run_rate<2>("v_fma_f64 x8 indep", 64, 2, d_out)) return 1;

@@ -23,6 +23,8 @@ out = (ctypes.c_ulonglong * 8)()
 dll.gatk_pairhmm_debug_phase_clocks(out, 1)
 res.compute()
 dll.gatk_pairhmm_debug_phase_clocks(out, 1)
+if out[7]:
+    print(f"wave lifetime: {out[4]} shader ticks / {out[7]} ticks of the 100 MHz counter -> {100.0 * out[4] / out[7]:.0f} MHz")
 names = ["decode+hap image", "row constants+table", "fill", "steady", "drain", "termination"]
 tot = sum(out[:6])
 print(f"tasks {out[6]}  cycles/task {tot / max(out[6], 1):.0f}  kernel_ms {hmm.stats()['fp32_kernel_ms']:.3f}")
