@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -134,11 +135,18 @@ struct gatk_pairhmm_resident {
     bool any_stream = false;
     DeviceBatch base{};  // pointers into d_arena
     const int32_t* d_neg_inf_idx = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // HIP events of the passes enqueued since the last wait (timing option): start, forward kernels
+    // begin / end, fp64 pass begin, end
+    using EventSet = std::array<hipEvent_t, 5>;
+    std::vector<EventSet> ev_pending, ev_free;
     void release() {
         for (DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_counters, &d_row_consts, &d_hap_stream, &d_raw_out, &d_rerun_flags}) b->release();
-        for (auto& e : ev)
-            if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        for (auto* v : {&ev_pending, &ev_free}) {
+            for (auto& set : *v)
+                for (auto& e : set)
+                    if (e) (void)hipEventDestroy(e);
+            v->clear();
+        }
     }
 };
 
@@ -584,9 +592,17 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = h->stream;
     const bool timing = h->timing && g_num_threads.load() == 1;
-    if (timing)
-        for (auto& e : R->ev)
-            if (!e) HIP_TRY(hipEventCreate(&e));
+    gatk_pairhmm_resident::EventSet ev{};
+    if (timing) {
+        if (!R->ev_free.empty()) {
+            ev = R->ev_free.back();
+            R->ev_free.pop_back();
+        } else {
+            for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+        }
+        R->ev_pending.push_back(ev);
+        HIP_TRY(hipEventRecord(ev[0], s));
+    }
     HIP_TRY(hipMemsetAsync(R->d_counters.p, 0, 256, s));
     DeviceBatch B = R->base;
     B.err_prob = h->d_err;
@@ -605,7 +621,7 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
         HIP_TRY(launch_expand_haps(B, s));
     }
     if (R->num_neg_inf > 0) HIP_TRY(launch_fill_neg_inf(B.out, R->d_neg_inf_idx, R->num_neg_inf, s));
-    if (timing) HIP_TRY(hipEventRecord(R->ev[0], s));
+    if (timing) HIP_TRY(hipEventRecord(ev[1], s));
     auto bucket_args = [&](size_t bi, int mode) {
         const Bucket& bk = R->buckets[bi];
         DeviceBatch L = B;
@@ -632,8 +648,9 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
         const int blocks = (bk.num_tasks + kWavesPerBlock - 1) / kWavesPerBlock;
         HIP_TRY(launch_forward(bucket_args(bi, mode), bk.rows_per_lane, mode, h->force_fp64, false, blocks, s));
     }
+    if (timing) HIP_TRY(hipEventRecord(ev[2], s));
     if (streaming) HIP_TRY(launch_finish_stream(B, s));
-    if (timing) HIP_TRY(hipEventRecord(R->ev[1], s));
+    if (timing) HIP_TRY(hipEventRecord(ev[3], s));
     if (!h->force_fp64) {
         for (size_t bi = 0; bi < R->buckets.size(); ++bi) {
             const Bucket& bk = R->buckets[bi];
@@ -641,7 +658,7 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
             HIP_TRY(launch_forward(bucket_args(bi, bk.emit_mode_fp64), bk.rows_per_lane, bk.emit_mode_fp64, true, true, blocks, s));
         }
     }
-    if (timing) HIP_TRY(hipEventRecord(R->ev[2], s));
+    if (timing) HIP_TRY(hipEventRecord(ev[4], s));
     R->computed = true;
     return GATK_PAIRHMM_OK;
 }
@@ -679,12 +696,19 @@ int finish_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
             for (int t : list) st.rerun_pairs += R->group_segs[group_of_task(R, bk, t)];
         }
     }
-    if (h->timing && g_num_threads.load() == 1 && R->ev[0]) {
-        float a = 0, b = 0;
-        HIP_TRY(hipEventElapsedTime(&a, R->ev[0], R->ev[1]));
-        HIP_TRY(hipEventElapsedTime(&b, R->ev[1], R->ev[2]));
-        st.fp32_kernel_ms = a; st.fp64_kernel_ms = b;
+    for (const auto& ev : R->ev_pending) {  // every pass enqueued since the last wait
+        float pre = 0, fwd = 0, fin = 0, rerun = 0;
+        HIP_TRY(hipEventElapsedTime(&pre, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&fwd, ev[1], ev[2]));
+        HIP_TRY(hipEventElapsedTime(&fin, ev[2], ev[3]));
+        HIP_TRY(hipEventElapsedTime(&rerun, ev[3], ev[4]));
+        st.fp32_kernel_ms += fwd;
+        st.fp64_kernel_ms += rerun;
+        st.aux_kernel_ms += pre + fin;
+        ++st.timed_passes;
+        R->ev_free.push_back(ev);
     }
+    R->ev_pending.clear();
     h->stats = st;
     if (counters[0] & 1) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "insert quality, deletion quality or gcp cannot be less than 0 (byte >= 128)");
     if (counters[0] & 2) return fail(GATK_PAIRHMM_INDEX_OUT_OF_BOUNDS, "base quality 255 is outside the 255-entry error-probability cache");
@@ -983,6 +1007,14 @@ int gatk_pairhmm_compute_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, int
         if (int rc = enqueue_compute(h, r)) return rc;
     if (sync) return finish_compute(h, r);
     return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_wait_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r) {
+    if (int rc = check_handle(h)) return rc;
+    if (!r) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "resident batch cannot be null");
+    if (r->total_pairs == 0) return GATK_PAIRHMM_OK;
+    if (!r->computed) return fail(GATK_PAIRHMM_ILLEGAL_STATE, "wait before compute_resident");
+    return finish_compute(h, r);
 }
 
 int gatk_pairhmm_download(gatk_pairhmm* h, gatk_pairhmm_resident* r, double* const* likelihoods) {

@@ -57,7 +57,8 @@ class CBatch(C.Structure):
 class CStats(C.Structure):
     _fields_ = [("pairs", C.c_int64), ("cells", C.c_int64), ("wave_tasks", C.c_int64), ("rerun_tasks", C.c_int64),
                 ("rerun_pairs", C.c_int64), ("fp32_kernel_ms", C.c_double), ("fp64_kernel_ms", C.c_double),
-                ("host_plan_ms", C.c_double), ("host_upload_ms", C.c_double)]
+                ("host_plan_ms", C.c_double), ("host_upload_ms", C.c_double), ("aux_kernel_ms", C.c_double),
+                ("timed_passes", C.c_int64)]
 
 
 # every symbol include/gatk_pairhmm.h declares
@@ -69,6 +70,7 @@ EXPORTS = [
     "gatk_pairhmm_get_stats", "gatk_pairhmm_last_error", "gatk_pairhmm_version", "gatk_pairhmm_device_count",
     "gatk_pairhmm_set_option", "gatk_pairhmm_upload", "gatk_pairhmm_compute_resident", "gatk_pairhmm_download",
     "gatk_pairhmm_resident_free", "gatk_pairhmm_get_stream", "gatk_pairhmm_resident_device_output",
+    "gatk_pairhmm_wait_resident",
 ]
 
 _lib = None
@@ -94,6 +96,7 @@ def load_library():
         L.gatk_pairhmm_compute_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.gatk_pairhmm_download.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.gatk_pairhmm_resident_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.gatk_pairhmm_wait_resident.argtypes = [C.c_void_p, C.c_void_p]
         L.gatk_pairhmm_get_stats.argtypes = [C.c_void_p, C.POINTER(CStats)]
         L.gatk_pairhmm_close.argtypes = [C.c_void_p]
         L.gatk_pairhmm_finalize_region.argtypes = [C.c_void_p]
@@ -172,6 +175,9 @@ class Resident:
 
     def compute(self, sync=True):
         _check(load_library().gatk_pairhmm_compute_resident(self.hmm._h, self.handle, 1 if sync else 0))
+
+    def wait(self):
+        _check(load_library().gatk_pairhmm_wait_resident(self.hmm._h, self.handle))
 
     def download(self):
         outs = [np.empty(nr * nh, dtype=np.float64) for nr, nh in self.shapes]

@@ -69,6 +69,9 @@ typedef struct gatk_pairhmm_stats {
     double fp64_kernel_ms;  /* device time of the fp64 rerun kernels (HIP events), 0 if not timed */
     double host_plan_ms;    /* host time spent checking, planning and packing the call */
     double host_upload_ms;  /* host time of the single host-to-device copy (including the wait for it) */
+    double aux_kernel_ms;   /* device time of the small kernels around them: validation, expansion of reads and
+                               haplotypes, conversion of the fp32 sums to log10 */
+    int64_t timed_passes;   /* passes the three *_kernel_ms sums cover: every compute_resident since the last wait */
 } gatk_pairhmm_stats;
 
 /* Constructor of a PairHMM instance on GPU `device` (replaces the JNI library's one-time
@@ -152,11 +155,14 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value);
  *   upload   : validate shapes, plan wave tasks, copy bytes and plan to the device
  *   compute  : enqueue validation + forward kernels (+ fp64 rerun) on the handle's stream;
  *              returns without waiting unless sync != 0
+ *   wait     : wait for the enqueued passes and check the device-side error word
  *   download : wait, check the device-side error word, copy region k's likelihoods out
  */
 int gatk_pairhmm_upload(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
                         gatk_pairhmm_resident** out);
 int gatk_pairhmm_compute_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, int32_t sync);
+/* Wait for every pass enqueued on r, report device-side input errors of the last one, refresh the stats. */
+int gatk_pairhmm_wait_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r);
 int gatk_pairhmm_download(gatk_pairhmm* h, gatk_pairhmm_resident* r, double* const* likelihoods);
 int gatk_pairhmm_resident_free(gatk_pairhmm* h, gatk_pairhmm_resident* r);
 /* The HIP stream (hipStream_t) the handle enqueues on, for callers that time it with events. */
