@@ -24,6 +24,9 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_CELL = 12          # 8 mul + 4 add of the linear-space three-state recurrence
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X: 256 CU x 4 SIMD x 32 lanes x 2 FLOP x 2.4 GHz
+# HBM bytes of one fp32 forward launch on the default workload, from PMC counters collected in a run
+# of their own (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_stream_kernel.txt); not measured live
+PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD = 2 * 10287.9e3 + 6858.8e3
 
 
 def cpu_baseline(batch, target_seconds=12.0):
@@ -130,7 +133,8 @@ def main():
                        "parallelism": f"independent batches on {world} GPU(s), host gather, no collective"},
             "roofline": {"bound": "valu", "bound_detail": "fp32 vector ALU (a recurrence: neither HBM- nor MFMA-bound)",
                          "kernel": "fwd_stream<10, 2> (fp32 forward pass)", "achieved": round(achieved, 2), "peak": PEAK_FP32_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
+                         "traffic": PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD if (args.reads, args.haps) == (4096, 64) else None,
                          "flop_per_cell": FLOP_PER_CELL, "kernel_ms": round(fp32_ms / steps, 4),
                          "kernel_gcups": round(batch.cells / kern_s / 1e9, 1)},
             "other_kernels_ms": round(aux_ms / steps, 4),

@@ -696,6 +696,12 @@ int finish_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
             for (int t : list) st.rerun_pairs += R->group_segs[group_of_task(R, bk, t)];
         }
     }
+    if (R->ev_pending.empty()) {  // nothing enqueued since the last wait: the timings of that wait still stand
+        st.fp32_kernel_ms = h->stats.fp32_kernel_ms;
+        st.fp64_kernel_ms = h->stats.fp64_kernel_ms;
+        st.aux_kernel_ms = h->stats.aux_kernel_ms;
+        st.timed_passes = h->stats.timed_passes;
+    }
     for (const auto& ev : R->ev_pending) {  // every pass enqueued since the last wait
         float pre = 0, fwd = 0, fin = 0, rerun = 0;
         HIP_TRY(hipEventElapsedTime(&pre, ev[0], ev[1]));

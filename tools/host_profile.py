@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from gatk_amd import pairhmm, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
@@ -37,5 +37,5 @@ for rep in range(3):
     st = hmm.stats()
     cells = sum(b.cells for b in regions)
     print(f"marshal {1e3 * (t1 - t0):.1f} ms | plan+upload {1e3 * (t2 - t1):.1f} ms | compute {1e3 * (t3 - t2):.1f} ms "
-          f"(kernels {st['fp32_kernel_ms'] + st['fp64_kernel_ms']:.1f} ms, {cells / (st['fp32_kernel_ms'] + st['fp64_kernel_ms']) / 1e6:.0f} GCUPS) | download {1e3 * (t4 - t3):.1f} ms | tasks {st['wave_tasks']}")
+          f"(kernels {st['fp32_kernel_ms'] + st['fp64_kernel_ms'] + st['aux_kernel_ms']:.1f} ms, {cells / (st['fp32_kernel_ms'] + st['fp64_kernel_ms'] + st['aux_kernel_ms']) / 1e6:.0f} GCUPS) | download {1e3 * (t4 - t3):.1f} ms | tasks {st['wave_tasks']}")
 hmm.close()

@@ -8,7 +8,7 @@ for path in sys.argv[1:]:
     with open(path) as f:
         for row in csv.DictReader(f):
             name = row["Kernel_Name"]
-            short = name.split("(")[0].split("::")[-1]
+            short = name.replace("(anonymous namespace)::", "").split("(")[0].split("::")[-1]
             acc[(short, row["Counter_Name"])].append(float(row["Counter_Value"]))
     print(path)
     for (k, c), v in sorted(acc.items()):
