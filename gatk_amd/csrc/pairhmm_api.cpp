@@ -188,27 +188,37 @@ double now_ms() {
 // Planner
 // ---------------------------------------------------------------------------------------------
 
-// Rows per lane for a region: minimise modelled issue slots, keeping enough waves in flight.
-// call_pairs: (read, haplotype) pairs of the whole call, all regions together: regions share launches,
-// so whether the GPU is full is a property of the call, not of one region.
-int choose_rows_per_lane(int max_read_len, int64_t num_reads, int64_t num_haps, double mean_hap_len, int64_t call_pairs,
-                         int forced) {
+// Rows per lane for a region: pack the region's reads (lengths sorted longest first) into wave-groups
+// for every candidate and take the one with the fewest modelled issue slots, keeping enough waves in
+// flight.  call_pairs: (read, haplotype) pairs of the whole call, all regions together: regions share
+// launches, so whether the GPU is full is a property of the call, not of one region.
+int choose_rows_per_lane(const std::vector<int>& lens_desc, int64_t num_haps, double mean_hap_len, int64_t call_pairs, int forced) {
+    const int max_read_len = lens_desc.empty() ? 1 : lens_desc.front();
     const int min_k = (max_read_len + 1 + kWave) / kWave;  // lanes * k >= len + 2 (a pad row in front, the sum row behind)
     if (forced >= min_k && rows_per_lane_supported(forced)) return forced;
     int best_k = kMaxRowsPerLane;
     double best = std::numeric_limits<double>::infinity();
     for (int k : kRowsPerLaneChoices) {
         if (k < min_k) continue;
-        if (k > 10 && best_k != kMaxRowsPerLane) break;  // beyond 10 rows the fp64 rerun kernel spills: only for long reads
-        const int lanes = (max_read_len + 1 + k) / k;
-        const int per_wave = std::max(1, kWave / lanes);
-        const double tasks = std::ceil(static_cast<double>(num_reads) / per_wave) * static_cast<double>(num_haps);
-        const double steps = mean_hap_len + lanes - 1;
-        const double slots = steps * (6.0 * k + 6.0);      // vector instructions per task
+        if (k > 12 && best_k != kMaxRowsPerLane) break;  // more rows cost a wave per SIMD: only for long reads
+        // the packing the planner will do: segments in order, a new wave-group when 64 lanes are full
+        int64_t groups = 0;
+        double group_steps = 0;
+        int used = kWave;
+        for (int len : lens_desc) {
+            const int seg = (len + 1 + k) / k;
+            if (used + seg > kWave) { ++groups; used = 0; group_steps += mean_hap_len + 1 + seg; }
+            used += seg;
+        }
+        const double per_wave = std::max(1.0, static_cast<double>(lens_desc.size()) / std::max<int64_t>(groups, 1));
+        double slots = group_steps * (5.0 * k + 6.0) * static_cast<double>(num_haps);  // vector instructions of the region
+        if (k > 10) slots *= 1.03;  // the fp64 pass spills beyond 10 rows
+        if (k > 12) slots *= 1.15;  // two waves per SIMD instead of three
+        const double tasks = static_cast<double>(groups) * static_cast<double>(num_haps);
         // two waves on each of the 1024 SIMDs saturate issue
         const double in_flight = std::min(std::max(tasks, static_cast<double>(call_pairs) / per_wave), 2048.0);
-        const double t = tasks * slots / in_flight;
-        if (t < best * 0.98) { best = t; best_k = k; }
+        const double t = slots / in_flight;
+        if (t < best * 0.99) { best = t; best_k = k; }
     }
     return best_k;
 }
@@ -301,7 +311,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     std::vector<SegDesc> segs;
     segs.reserve(static_cast<size_t>(total_reads));
     std::vector<int32_t> neg_inf_idx;
-    std::vector<int> order;
+    std::vector<int> order, lens_desc;
     std::vector<ReadInfo> read_info(static_cast<size_t>(total_reads), ReadInfo{0, 0, 0, -1});
     std::vector<StreamDesc> stream_descs;
     bool any_hap_n = false, any_hap_other = false;
@@ -340,12 +350,14 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
                     neg_inf_idx.push_back(static_cast<int32_t>(R->region_out_off[k] + static_cast<int64_t>(r) * nh + a));
         }
         read_max_all = std::max(read_max_all, read_max);
-        const int K = choose_rows_per_lane(read_max, nr, nh, static_cast<double>(hap_total) / nh, call_pairs, h->force_rows_per_lane);
-        rp.K = K;
         // wave-groups: longest reads first, filled lane segment by lane segment up to 64 lanes
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
             return (b.read_offsets[x + 1] - b.read_offsets[x]) > (b.read_offsets[y + 1] - b.read_offsets[y]);
         });
+        lens_desc.clear();
+        for (int r : order) lens_desc.push_back(b.read_offsets[r + 1] - b.read_offsets[r]);
+        const int K = choose_rows_per_lane(lens_desc, nh, static_cast<double>(hap_total) / nh, call_pairs, h->force_rows_per_lane);
+        rp.K = K;
         rp.group_begin = static_cast<int>(groups.size());
         size_t pos = 0;
         int max_fill = 0;

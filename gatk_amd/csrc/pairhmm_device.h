@@ -6,7 +6,7 @@ namespace pairhmm_hip {
 
 // Read rows a lane can own: the template instantiations of the forward kernel.
 constexpr int kMaxRowsPerLane = 16;
-constexpr int kRowsPerLaneChoices[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16};
+constexpr int kRowsPerLaneChoices[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16};
 inline bool rows_per_lane_supported(int k) {
     for (int c : kRowsPerLaneChoices)
         if (c == k) return true;

@@ -486,7 +486,10 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
 // Steps are taken four at a time.  A block of four steps in which no lane is at a gap runs the
 // unmasked column code; a block that has some lane at a gap takes the masked path.  Haplotype codes
 // come straight from global memory, kStreamAhead blocks ahead of their use.
-constexpr int kStreamAhead = 4;
+#ifndef PAIRHMM_STREAM_AHEAD
+#define PAIRHMM_STREAM_AHEAD 4
+#endif
+constexpr int kStreamAhead = PAIRHMM_STREAM_AHEAD;
 
 struct StreamLane {
     int next_gap;  // stream position (relative to the run's first gap) of the next gap this lane meets
@@ -887,8 +890,11 @@ hipError_t launch_t(const DeviceBatch& B, int K, int mode, bool list_mode, int b
         case 6: return launch_k<T, 6>(B, mode, list_mode, blocks, stream);
         case 7: return launch_k<T, 7>(B, mode, list_mode, blocks, stream);
         case 8: return launch_k<T, 8>(B, mode, list_mode, blocks, stream);
+        case 9: return launch_k<T, 9>(B, mode, list_mode, blocks, stream);
         case 10: return launch_k<T, 10>(B, mode, list_mode, blocks, stream);
+        case 11: return launch_k<T, 11>(B, mode, list_mode, blocks, stream);
         case 12: return launch_k<T, 12>(B, mode, list_mode, blocks, stream);
+        case 14: return launch_k<T, 14>(B, mode, list_mode, blocks, stream);
         case 16: return launch_k<T, 16>(B, mode, list_mode, blocks, stream);
         default: return hipErrorInvalidValue;
     }
@@ -924,8 +930,11 @@ hipError_t launch_stream(const DeviceBatch& B, int rows_per_lane, int emit_mode,
         case 6: return launch_stream_k<6>(B, emit_mode, blocks, stream);
         case 7: return launch_stream_k<7>(B, emit_mode, blocks, stream);
         case 8: return launch_stream_k<8>(B, emit_mode, blocks, stream);
+        case 9: return launch_stream_k<9>(B, emit_mode, blocks, stream);
         case 10: return launch_stream_k<10>(B, emit_mode, blocks, stream);
+        case 11: return launch_stream_k<11>(B, emit_mode, blocks, stream);
         case 12: return launch_stream_k<12>(B, emit_mode, blocks, stream);
+        case 14: return launch_stream_k<14>(B, emit_mode, blocks, stream);
         case 16: return launch_stream_k<16>(B, emit_mode, blocks, stream);
         default: return hipErrorInvalidValue;
     }

@@ -58,16 +58,20 @@ def test_config_c1_full(hmm, oracle):
     assert st["pairs"] == 128 * 16 and st["cells"] == b.cells
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8])
-def test_every_rows_per_lane_variant(hmm, oracle, k):
-    # reads of 1..60 bases (k = 1 needs <= 64 rows); every lane-segment packing is exercised
+@pytest.mark.parametrize("stream_mode", [-1, 0])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16])
+def test_every_rows_per_lane_variant(hmm, oracle, k, stream_mode):
+    # reads of 1..60 bases (k = 1 needs <= 62 rows); every lane-segment packing is exercised, with
+    # haplotype runs and with one haplotype per work item
     b = synth.make_batch(40, 5, 60, 130, seed=30 + k, len_jitter=59, gop_model="random")
     want = ref(oracle, b)
     hmm.set_option("force_rows_per_lane", k)
+    hmm.set_option("stream_mode", stream_mode)
     try:
         assert_parity(hmm.compute_batch(b), want)
     finally:
         hmm.set_option("force_rows_per_lane", 0)
+        hmm.set_option("stream_mode", -1)
 
 
 def test_long_read_indel_stress_uses_the_fp64_rerun(hmm, oracle):
@@ -406,7 +410,7 @@ def test_runs_and_single_haplotype_items_agree(hmm, oracle):
     np.testing.assert_allclose(runs, compare, rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("k", [1, 2, 4, 8, 10, 16])
+@pytest.mark.parametrize("k", [1, 2, 4, 8, 9, 10, 11, 12, 14, 16])
 def test_runs_with_haplotypes_shorter_than_the_pipeline(hmm, oracle, k):
     # haplotypes of 1..12 bases against reads of up to 60 bases: with few rows per lane a read spans more
     # lanes than a haplotype has columns, so several gaps are inside the wave at once
