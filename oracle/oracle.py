@@ -55,6 +55,9 @@ def lib():
         L.oracle_qualToTransProbs.restype = C.c_int
         L.oracle_qualToTransProbsLog10.argtypes = [f64p, C.c_uint8, C.c_uint8, C.c_uint8]
         L.oracle_qualToTransProbsLog10.restype = C.c_int
+        L.simd_pairhmm_batch.argtypes = [C.c_int, C.c_int, u8p, u8p, u8p, u8p, u8p, i32p, u8p, i32p, f64p, C.c_int, C.POINTER(C.c_int64)]
+        L.simd_pairhmm_batch.restype = C.c_int
+        L.simd_pairhmm_isa.restype = C.c_char_p
         L.oracle_init()
         _lib = L
     return _lib
@@ -98,3 +101,21 @@ def compute_likelihoods(batch, mode=LOGLESS, fast_threads=0):
     else:
         rc = lib().oracle_computeLikelihoods(mode, nr, nh, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], op)
     return rc, out
+
+
+def simd_compute_likelihoods(batch, threads=1):
+    """The vectorised fp32-with-fp64-redo CPU baseline (pairhmm_simd.cpp) on a packed batch.
+    Returns (rc, out[numReads, numHaps], pairs redone in fp64)."""
+    nr, nh = len(batch.read_offsets) - 1, len(batch.hap_offsets) - 1
+    out = np.full((nr, nh), np.nan, dtype=np.float64)
+    keep = [_u8(batch.read_bases), _u8(batch.read_quals), _u8(batch.ins_gop), _u8(batch.del_gop), _u8(batch.gcp),
+            _i32(batch.read_offsets), _u8(batch.hap_bases), _i32(batch.hap_offsets)]
+    p = [k[1] for k in keep]
+    redo = C.c_int64(0)
+    rc = lib().simd_pairhmm_batch(nr, nh, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7],
+                                  out.ctypes.data_as(C.POINTER(C.c_double)), threads, C.byref(redo))
+    return rc, out, redo.value
+
+
+def simd_isa():
+    return lib().simd_pairhmm_isa().decode()

@@ -146,3 +146,37 @@ def test_underflow_to_minus_infinity_is_accepted(oracle):
     assert rc == 0 and out[0, 0] == -np.inf
     rc, ex = oracle.compute_likelihoods(b, oracle.EXACT)
     assert rc == 0 and np.isfinite(ex[0, 0]) and ex[0, 0] < -3000
+
+
+# ---- the vectorised timing baseline (oracle/pairhmm_simd.cpp) against the scalar restatement ----
+
+@pytest.mark.parametrize("shape", ["c1", "c5", "ragged", "wild"])
+def test_simd_baseline_matches_the_scalar_oracle(oracle, shape):
+    from gatk_amd import synth
+    from gatk_amd.batch import pack
+    if shape == "c1":
+        b = synth.make_batch(24, 16, 101, 400, seed=1)
+    elif shape == "c5":
+        b = synth.config_c5(num_reads=16, num_haps=8)
+    elif shape == "ragged":
+        b = synth.make_batch(30, 37, 80, 200, seed=3, len_jitter=60, hap_len_jitter=120, gop_model="random")
+    else:
+        b = pack([("ACNTACGT", [30] * 8, [40] * 8, [40] * 8, [10] * 8), ("", [], [], [], []), ("N", [20], [45], [45], [10])],
+                 ["ACGTACGT", "ANNTACG", "TTTTTTTTTTTT"])
+    rc, want = oracle.compute_likelihoods(b, oracle.LOGLESS)
+    rc2, got, redo = oracle.simd_compute_likelihoods(b, threads=2)
+    assert rc == 0 and rc2 == 0
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)
+    assert np.abs(got[fin] - want[fin]).max() <= 1e-3  # fp32 with fp64 redo: the bound stated for the path
+    if shape == "c5":
+        assert redo > 0  # the high-indel shape exercises the fp64 redo
+    assert oracle.simd_isa() in ("avx512", "avx2", "generic")
+
+
+def test_simd_baseline_reports_the_reference_input_errors(oracle):
+    from gatk_amd.batch import pack
+    bad_gop = pack([("ACGT", [30] * 4, [200, 40, 40, 40], [40] * 4, [10] * 4)], ["ACGT"])
+    assert oracle.simd_compute_likelihoods(bad_gop)[0] == oracle.compute_likelihoods(bad_gop, oracle.LOGLESS)[0] != 0
+    bad_qual = pack([("ACGT", [255, 30, 30, 30], [40] * 4, [40] * 4, [10] * 4)], ["ACGT"])
+    assert oracle.simd_compute_likelihoods(bad_qual)[0] == oracle.compute_likelihoods(bad_qual, oracle.LOGLESS)[0] != 0
