@@ -5,7 +5,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <emmintrin.h>
+
 #include <array>
+#include <thread>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -116,6 +119,7 @@ struct Bucket {
 
 struct gatk_pairhmm_resident {
     // ---- host-side plan ----
+    hipStream_t stream = nullptr;  // every copy and kernel of this batch is ordered on it
     int num_regions = 0;
     std::vector<int64_t> region_out_off;  // [num_regions + 1] offsets into the concatenated output
     int64_t total_pairs = 0, cells = 0, total_tasks = 0;
@@ -139,6 +143,7 @@ struct gatk_pairhmm_resident {
     // begin / end, fp64 pass begin, end
     using EventSet = std::array<hipEvent_t, 5>;
     std::vector<EventSet> ev_pending, ev_free;
+    gatk_pairhmm_stats last_timing{};
     void release() {
         for (DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_counters, &d_row_consts, &d_hap_stream, &d_raw_out, &d_rerun_flags}) b->release();
         for (auto* v : {&ev_pending, &ev_free}) {
@@ -165,7 +170,11 @@ struct gatk_pairhmm {
     int max_stream_haps = kMaxStreamHaps;
     bool force_fp64 = false;
     bool timing = false;
-    gatk_pairhmm_resident scratch;  // buffers reused by the host-pointer entry points
+    // buffers reused by the host-pointer entry points; two of them, each with a stream of its own, so that
+    // a call over many regions can plan and copy one part while the kernels of the part before it run
+    gatk_pairhmm_resident scratch, scratch2;
+    hipStream_t stream2 = nullptr;
+    int64_t pipeline_pairs = 131072;  // pairs per part of such a call; 0: never split a call
     PinnedBuf stage_in, stage_out;  // pinned staging shared by every upload / download on this handle
     std::vector<double> likelihood_array;
     gatk_pairhmm_stats stats{};
@@ -268,6 +277,57 @@ struct ArenaLayout {
     }
 };
 
+// Which letters does a haplotype use?  has_n: an 'N'; has_other: anything outside A, C, G, T, N.
+void scan_alphabet(const uint8_t* p, int len, bool& has_n, bool& has_other) {
+    int x = 0;
+    const __m128i a = _mm_set1_epi8('A'), c = _mm_set1_epi8('C'), g = _mm_set1_epi8('G'), t = _mm_set1_epi8('T'), n = _mm_set1_epi8('N');
+    __m128i all_ok = _mm_set1_epi8(-1), any_n = _mm_setzero_si128();
+    for (; x + 16 <= len; x += 16) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + x));
+        const __m128i is_n = _mm_cmpeq_epi8(v, n);
+        const __m128i acgt = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, a), _mm_cmpeq_epi8(v, c)), _mm_or_si128(_mm_cmpeq_epi8(v, g), _mm_cmpeq_epi8(v, t)));
+        any_n = _mm_or_si128(any_n, is_n);
+        all_ok = _mm_and_si128(all_ok, _mm_or_si128(acgt, is_n));
+    }
+    if (_mm_movemask_epi8(any_n) != 0) has_n = true;
+    if (_mm_movemask_epi8(all_ok) != 0xffff) has_other = true;
+    for (; x < len; ++x) {
+        const uint8_t b = p[x];
+        if (b == 'N') has_n = true;
+        else if (b != 'A' && b != 'C' && b != 'G' && b != 'T') has_other = true;
+    }
+}
+
+// A memcpy into the staging buffer.
+struct CopyJob {
+    uint8_t* dst;
+    const uint8_t* src;
+    size_t bytes;
+};
+
+// Large calls are bound by these copies (five bytes per read base): split them over a few threads.
+void run_copies(const std::vector<CopyJob>& jobs) {
+    size_t total = 0;
+    for (const CopyJob& j : jobs) total += j.bytes;
+    const int threads = total < (size_t{4} << 20) ? 1 : static_cast<int>(std::min<size_t>(4, total >> 21));
+    auto run = [&](size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; ++k) memcpy(jobs[k].dst, jobs[k].src, jobs[k].bytes);
+    };
+    if (threads <= 1) { run(0, jobs.size()); return; }
+    std::vector<std::thread> pool;
+    size_t begin = 0, acc = 0;
+    int started = 0;
+    for (size_t k = 0; k < jobs.size(); ++k) {
+        acc += jobs[k].bytes;
+        if (acc >= total / threads && started + 1 < threads) {
+            pool.emplace_back(run, begin, k + 1);
+            begin = k + 1; acc = 0; ++started;
+        }
+    }
+    run(begin, jobs.size());
+    for (auto& t : pool) t.join();
+}
+
 // Per-region planning record (host only).
 struct RegionPlan {
     int region = 0, K = 0, nr = 0, nh = 0;
@@ -288,6 +348,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     R->buckets.clear(); R->descs.clear(); R->group_segs.clear();
     R->any_stream = false;
     R->computed = false;
+    R->last_timing = gatk_pairhmm_stats{};
 
     // ---- pass 1: sizes, rows per lane, wave-groups ------------------------------------------------
     int64_t call_pairs = 0, total_reads = 0, total_haps = 0, total_read_bytes = 0, hap_pool_bytes = 0;
@@ -330,12 +391,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             const int o = b.hap_offsets[a], len = b.hap_offsets[a + 1] - o;
             hap_total += len;
             rp.hap_max = std::max(rp.hap_max, len);
-            if (!any_hap_other)
-                for (int x = 0; x < len; ++x) {
-                    const uint8_t c = b.hap_bases[o + x];
-                    if (c == 'N') any_hap_n = true;
-                    else if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { any_hap_other = true; break; }
-                }
+            if (!any_hap_other) scan_alphabet(b.hap_bases + o, len, any_hap_n, any_hap_other);
         }
         hap_max_all = std::max(hap_max_all, rp.hap_max);
         order.clear();
@@ -515,17 +571,19 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     size_t rcur = 0, hcur = 0;
     int ri = 0, hi = 0;
     roff[0] = 0;
+    std::vector<CopyJob> copies;  // the bulk of the bytes: done at the end, on several threads when it pays
+    copies.reserve(static_cast<size_t>(num_regions) * 5);
     for (int k = 0; k < num_regions; ++k) {
         const gatk_pairhmm_batch& b = regions[k];
         const int nr = b.num_reads, nh = nr == 0 ? 0 : b.num_haps;
         if (nr == 0 || nh == 0) continue;
         const int bo = b.read_offsets[0];
         const size_t total = static_cast<size_t>(b.read_offsets[nr] - bo);
-        memcpy(S + o_rb + rcur, b.read_bases + bo, total);
-        memcpy(S + o_rq + rcur, b.read_quals + bo, total);
-        memcpy(S + o_ri + rcur, b.ins_gop + bo, total);
-        memcpy(S + o_rd + rcur, b.del_gop + bo, total);
-        memcpy(S + o_rg + rcur, b.gcp + bo, total);
+        copies.push_back({S + o_rb + rcur, b.read_bases + bo, total});
+        copies.push_back({S + o_rq + rcur, b.read_quals + bo, total});
+        copies.push_back({S + o_ri + rcur, b.ins_gop + bo, total});
+        copies.push_back({S + o_rd + rcur, b.del_gop + bo, total});
+        copies.push_back({S + o_rg + rcur, b.gcp + bo, total});
         for (int r = 0; r < nr; ++r) {
             rout[ri] = static_cast<int32_t>(R->region_out_off[k] + static_cast<int64_t>(r) * nh);
             roff[++ri] = static_cast<int32_t>(rcur + (b.read_offsets[r + 1] - bo));
@@ -545,6 +603,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         }
     }
     memset(S + o_hpool + hcur, 0, 32);
+    run_copies(copies);
     if (!groups.empty()) memcpy(S + o_groups, groups.data(), groups.size() * sizeof(GroupDesc));
     if (!segs.empty()) memcpy(S + o_segs, segs.data(), segs.size() * sizeof(SegDesc));
     if (!R->descs.empty()) memcpy(S + o_descs, R->descs.data(), R->descs.size() * sizeof(RegionDesc));
@@ -555,7 +614,8 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     if (R->hap_stream_entries >= (size_t{1} << 31)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "more than 2^31 haplotype bases in one call");
     const double t_planned = now_ms();
 
-    hipStream_t s = h->stream;
+    if (!R->stream) R->stream = h->stream;
+    hipStream_t s = R->stream;
     HIP_TRY(R->d_arena.ensure(L.size));
     HIP_TRY(R->d_out.ensure(std::max<size_t>(static_cast<size_t>(call_pairs) * sizeof(double), 16)));
     HIP_TRY(R->d_rerun_lists.ensure(std::max<size_t>(static_cast<size_t>(total_tasks) * sizeof(int32_t), 16)));
@@ -602,7 +662,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
 
 int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     HIP_TRY(hipSetDevice(h->device));
-    hipStream_t s = h->stream;
+    hipStream_t s = R->stream;
     const bool timing = h->timing && g_num_threads.load() == 1;
     gatk_pairhmm_resident::EventSet ev{};
     if (timing) {
@@ -689,7 +749,7 @@ int group_of_task(const gatk_pairhmm_resident* R, const Bucket& bk, int task) {
 // Wait for the stream, turn the device error word into the reference's exception code, fill stats.
 int finish_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipStreamSynchronize(R->stream));
     int32_t counters[1 + kMaxBuckets] = {0};
     HIP_TRY(hipMemcpy(counters, R->d_counters.p, sizeof counters, hipMemcpyDeviceToHost));
     gatk_pairhmm_stats st{};
@@ -708,11 +768,11 @@ int finish_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
             for (int t : list) st.rerun_pairs += R->group_segs[group_of_task(R, bk, t)];
         }
     }
-    if (R->ev_pending.empty()) {  // nothing enqueued since the last wait: the timings of that wait still stand
-        st.fp32_kernel_ms = h->stats.fp32_kernel_ms;
-        st.fp64_kernel_ms = h->stats.fp64_kernel_ms;
-        st.aux_kernel_ms = h->stats.aux_kernel_ms;
-        st.timed_passes = h->stats.timed_passes;
+    if (R->ev_pending.empty()) {  // nothing timed since the last wait on this batch: its timings still stand
+        st.fp32_kernel_ms = R->last_timing.fp32_kernel_ms;
+        st.fp64_kernel_ms = R->last_timing.fp64_kernel_ms;
+        st.aux_kernel_ms = R->last_timing.aux_kernel_ms;
+        st.timed_passes = R->last_timing.timed_passes;
     }
     for (const auto& ev : R->ev_pending) {  // every pass enqueued since the last wait
         float pre = 0, fwd = 0, fin = 0, rerun = 0;
@@ -727,6 +787,7 @@ int finish_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
         R->ev_free.push_back(ev);
     }
     R->ev_pending.clear();
+    R->last_timing = st;
     h->stats = st;
     if (counters[0] & 1) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "insert quality, deletion quality or gcp cannot be less than 0 (byte >= 128)");
     if (counters[0] & 2) return fail(GATK_PAIRHMM_INDEX_OUT_OF_BOUNDS, "base quality 255 is outside the 255-entry error-probability cache");
@@ -797,6 +858,7 @@ int gatk_pairhmm_create(int device, gatk_pairhmm** out) {
     gatk_pairhmm* h = new gatk_pairhmm();
     h->device = device;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
     int cus = 0;
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (cus > 0) h->wave_slots = cus * 12;
@@ -827,10 +889,67 @@ int gatk_pairhmm_initialize(gatk_pairhmm* h, int32_t read_max_length, int32_t ha
 int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
                                  double* const* likelihoods) {
     if (int rc = check_handle(h)) return rc;
-    if (int rc = plan_and_upload(h, &h->scratch, num_regions, regions)) return rc;
-    if (h->scratch.total_pairs == 0) { h->stats = gatk_pairhmm_stats{}; return GATK_PAIRHMM_OK; }
-    if (int rc = enqueue_compute(h, &h->scratch)) return rc;
-    return download_into(h, &h->scratch, likelihoods);
+    if (num_regions < 0 || (num_regions > 0 && !regions)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "regions cannot be null");
+    // parts of about pipeline_pairs pairs, cut between regions
+    std::vector<int> cuts{0};
+    if (h->pipeline_pairs > 0) {
+        int64_t acc = 0;
+        for (int k = 0; k < num_regions; ++k) {
+            if (regions[k].num_reads > 0 && regions[k].num_haps > 0) acc += static_cast<int64_t>(regions[k].num_reads) * regions[k].num_haps;
+            if (acc >= h->pipeline_pairs && k + 1 < num_regions) { cuts.push_back(k + 1); acc = 0; }
+        }
+    }
+    cuts.push_back(num_regions);
+    if (cuts.size() <= 2) {
+        if (int rc = plan_and_upload(h, &h->scratch, num_regions, regions)) return rc;
+        if (h->scratch.total_pairs == 0) { h->stats = gatk_pairhmm_stats{}; return GATK_PAIRHMM_OK; }
+        if (int rc = enqueue_compute(h, &h->scratch)) return rc;
+        return download_into(h, &h->scratch, likelihoods);
+    }
+    // part p is planned and copied while the kernels of part p - 1 run; its results are fetched while the
+    // kernels of part p + 1 run
+    h->scratch.stream = h->stream;
+    h->scratch2.stream = h->stream2;
+    gatk_pairhmm_resident* slot[2] = {&h->scratch, &h->scratch2};
+    gatk_pairhmm_stats total{};
+    int rc = GATK_PAIRHMM_OK;
+    const int parts = static_cast<int>(cuts.size()) - 1;
+    auto fetch = [&](int p) {
+        gatk_pairhmm_resident* R = slot[p & 1];
+        const int r = R->total_pairs > 0 ? download_into(h, R, likelihoods ? likelihoods + cuts[p] : nullptr) : GATK_PAIRHMM_OK;
+        if (R->total_pairs > 0) {
+            const gatk_pairhmm_stats& st = h->stats;
+            total.pairs += st.pairs; total.cells += st.cells; total.wave_tasks += st.wave_tasks;
+            total.rerun_tasks += st.rerun_tasks; total.rerun_pairs += st.rerun_pairs;
+            total.fp32_kernel_ms += st.fp32_kernel_ms; total.fp64_kernel_ms += st.fp64_kernel_ms; total.aux_kernel_ms += st.aux_kernel_ms;
+            total.timed_passes += st.timed_passes;
+        }
+        total.host_plan_ms += R->plan_ms; total.host_upload_ms += R->upload_ms;
+        return r;
+    };
+    int fetched = 0;  // parts [0, fetched) are done; parts [fetched, enqueued) are in flight
+    int enqueued = 0;
+    for (int p = 0; p < parts && rc == GATK_PAIRHMM_OK; ++p) {
+        gatk_pairhmm_resident* R = slot[p & 1];
+        rc = plan_and_upload(h, R, cuts[p + 1] - cuts[p], regions + cuts[p]);
+        if (rc == GATK_PAIRHMM_OK && R->total_pairs > 0) rc = enqueue_compute(h, R);
+        if (rc == GATK_PAIRHMM_OK) enqueued = p + 1;
+        if (rc == GATK_PAIRHMM_OK && p >= 1) { rc = fetch(p - 1); fetched = p; }
+    }
+    if (rc == GATK_PAIRHMM_OK && fetched < enqueued) { rc = fetch(enqueued - 1); fetched = enqueued; }
+    if (rc != GATK_PAIRHMM_OK) {  // leave nothing in flight on buffers the next call will reuse
+        const std::string msg = g_last_error;
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->stream2);
+        for (auto* R : slot) {
+            for (auto& ev : R->ev_pending) R->ev_free.push_back(ev);
+            R->ev_pending.clear();
+        }
+        g_last_error = msg;
+        return rc;
+    }
+    h->stats = total;
+    return GATK_PAIRHMM_OK;
 }
 
 int gatk_pairhmm_compute_likelihoods(gatk_pairhmm* h, const gatk_pairhmm_batch* batch, double* likelihoods) {
@@ -971,12 +1090,15 @@ int gatk_pairhmm_close(gatk_pairhmm* h) {
     if (!h) return GATK_PAIRHMM_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     h->scratch.release();
+    h->scratch2.release();
     h->stage_in.release();
     h->stage_out.release();
     if (h->d_err) (void)hipFree(h->d_err);
     if (h->d_mm) (void)hipFree(h->d_mm);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     delete h;
     return GATK_PAIRHMM_OK;
 }
@@ -998,6 +1120,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
     else if (n == "emit_mode") h->emit_mode = static_cast<int>(value);
     else if (n == "timing") h->timing = value != 0;
     else if (n == "stream_mode") h->stream_mode = static_cast<int>(value);
+    else if (n == "pipeline_pairs") h->pipeline_pairs = std::max<int64_t>(0, static_cast<int64_t>(value));
     else if (n == "max_stream_haps") h->max_stream_haps = std::max(1, static_cast<int>(value));
     else return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "unknown option " + n);
     return GATK_PAIRHMM_OK;

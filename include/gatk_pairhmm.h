@@ -144,7 +144,9 @@ int gatk_pairhmm_device_count(int32_t* count);
  * "force_fp64" (1 = score everything in fp64), "emit_mode" (-1 = automatic, 0 = always compare bases
  * instead of using the per-wave emission table), "timing" (1 = fill the *_kernel_ms stats),
  * "stream_mode" (-1 = automatic: a wave scores a run of haplotypes back to back; 0 = one haplotype per
- * work item), "max_stream_haps" (longest run, 1..16).  Planning options take effect at the next
+ * work item), "max_stream_haps" (longest run, 1..16), "pipeline_pairs" (default 131072: a compute_regions call with more
+ * pairs is cut between regions into parts of about that many pairs, and one part is planned and copied while
+ * the kernels of the part before it run; 0 = never cut).  Planning options take effect at the next
  * upload or host-pointer call. */
 int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value);
 

@@ -447,3 +447,39 @@ def test_runs_across_regions_with_n_in_haplotypes(hmm, oracle):
     outs = hmm.compute_regions(regions)
     for b, o in zip(regions, outs):
         assert_parity(o, ref(oracle, b))
+
+
+def test_many_region_call_in_overlapped_parts(hmm, oracle):
+    regions = synth.make_regions(40, seed=21, coverage=6, read_len=90)
+    regions.insert(7, pack([], ["ACGT"]))
+    whole = with_options_pipeline(hmm, 0, lambda: hmm.compute_regions(regions))
+    for pairs in (1, 300, 5000):  # one region per part; a few regions per part; two or three parts
+        parts = with_options_pipeline(hmm, pairs, lambda: hmm.compute_regions(regions))
+        for a, b in zip(whole, parts):
+            np.testing.assert_array_equal(a, b)
+    st = with_options_pipeline(hmm, 300, lambda: (hmm.compute_regions(regions), hmm.stats())[1])
+    assert st["pairs"] == sum(b.num_reads * b.num_haps for b in regions)
+    assert st["cells"] == sum(b.cells for b in regions)
+    for b, o in zip(regions[:6], whole[:6]):
+        assert_parity(o, ref(oracle, b))
+
+
+def test_error_in_a_later_part_of_an_overlapped_call(hmm):
+    regions = synth.make_regions(12, seed=22, coverage=5, read_len=80)
+    bad = regions[8]
+    q = bad.read_quals.copy()
+    q[3] = 255
+    regions[8] = Batch(bad.read_bases, q, bad.ins_gop, bad.del_gop, bad.gcp, bad.read_offsets, bad.hap_bases, bad.hap_offsets)
+    with pytest.raises(pairhmm.ArrayIndexOutOfBoundsException):
+        with_options_pipeline(hmm, 1, lambda: hmm.compute_regions(regions))
+    # the handle is usable afterwards
+    good = synth.make_regions(3, seed=23, coverage=5, read_len=80)
+    assert all(np.isfinite(o).all() for o in hmm.compute_regions(good))
+
+
+def with_options_pipeline(hmm, pairs, fn):
+    hmm.set_option("pipeline_pairs", pairs)
+    try:
+        return fn()
+    finally:
+        hmm.set_option("pipeline_pairs", 131072)
