@@ -31,6 +31,7 @@ int stream_lds_bytes_per_wave(int rows_per_lane, int emit_mode);
 hipError_t launch_stream(const DeviceBatch& B, int rows_per_lane, int emit_mode, hipStream_t stream);
 hipError_t launch_expand_haps(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_finish_stream(const DeviceBatch& B, hipStream_t stream);
+hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int blocks, hipStream_t stream);
 hipError_t launch_validate(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_expand_reads(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_fill_neg_inf(double* out, const int32_t* idx, int n, hipStream_t stream);
@@ -113,6 +114,9 @@ struct Bucket {
     // fp32 stream pass (table modes only): haplotype runs instead of single haplotypes
     bool stream = false;
     int stream_desc_begin = 0, num_stream_descs = 0, num_stream_tasks = 0;
+    int64_t pair_begin = 0, num_pairs = 0;  // its part of the list of pairs queued for the fp64 pair pass
+    int pair_rows_per_lane = 1;             // rows per lane of the fp64 pair pass (its own choice, see plan)
+    int slot_lanes = 1;                     // lanes a pair gets there
 };
 
 }  // namespace
@@ -134,9 +138,10 @@ struct gatk_pairhmm_resident {
     DevBuf d_arena;  // every input array of the call, one H2D copy
     DevBuf d_out, d_rerun_lists, d_counters;
     DevBuf d_row_consts;  // fp32 row constants of every read, written on the device
-    DevBuf d_hap_stream, d_raw_out, d_rerun_flags;  // fp32 stream pass
+    DevBuf d_hap_stream, d_raw_out, d_pair_lists;  // fp32 stream pass and the fp64 pair pass behind it
     size_t hap_stream_entries = 0;
     bool any_stream = false;
+    bool streamed = false;  // the last pass enqueued used the stream pass and the fp64 pair pass
     DeviceBatch base{};  // pointers into d_arena
     const int32_t* d_neg_inf_idx = nullptr;
     // HIP events of the passes enqueued since the last wait (timing option): start, forward kernels
@@ -145,7 +150,7 @@ struct gatk_pairhmm_resident {
     std::vector<EventSet> ev_pending, ev_free;
     gatk_pairhmm_stats last_timing{};
     void release() {
-        for (DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_counters, &d_row_consts, &d_hap_stream, &d_raw_out, &d_rerun_flags}) b->release();
+        for (DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_counters, &d_row_consts, &d_hap_stream, &d_raw_out, &d_pair_lists}) b->release();
         for (auto* v : {&ev_pending, &ev_free}) {
             for (auto& set : *v)
                 for (auto& e : set)
@@ -335,6 +340,7 @@ struct RegionPlan {
     int hap_begin = 0;    // global index of its first haplotype
     int group_begin = 0, num_groups = 0;
     int hap_max = 0, cost = 0;
+    int read_max = 0;
 };
 
 int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, const gatk_pairhmm_batch* regions) {
@@ -373,7 +379,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     segs.reserve(static_cast<size_t>(total_reads));
     std::vector<int32_t> neg_inf_idx;
     std::vector<int> order, lens_desc;
-    std::vector<ReadInfo> read_info(static_cast<size_t>(total_reads), ReadInfo{0, 0, 0, -1});
+    std::vector<ReadInfo> read_info(static_cast<size_t>(total_reads), ReadInfo{0, 0, -1, 0});
     std::vector<StreamDesc> stream_descs;
     bool any_hap_n = false, any_hap_other = false;
     int64_t cells = 0;
@@ -406,6 +412,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
                     neg_inf_idx.push_back(static_cast<int32_t>(R->region_out_off[k] + static_cast<int64_t>(r) * nh + a));
         }
         read_max_all = std::max(read_max_all, read_max);
+        rp.read_max = read_max;
         // wave-groups: longest reads first, filled lane segment by lane segment up to 64 lanes
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
             return (b.read_offsets[x + 1] - b.read_offsets[x]) > (b.read_offsets[y + 1] - b.read_offsets[y]);
@@ -426,7 +433,6 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
                 const int seg = (len + 1 + K) / K;  // rows >= len + 2: a pad row in front, the sum row behind
                 if (used + seg > kWave) break;
                 segs.push_back(SegDesc{rp.read_begin + r, static_cast<uint8_t>(used), static_cast<uint8_t>(seg), static_cast<uint16_t>(len)});
-                read_info[rp.read_begin + r].task_base = static_cast<int32_t>(groups.size()) - rp.group_begin;  // group within the region, for now
                 used += seg;
                 max_seg = std::max(max_seg, seg);
                 ++g.num_segs; ++pos;
@@ -456,7 +462,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     std::stable_sort(by_cost.begin(), by_cost.end(), [&](int x, int y) {
         return plans[x].K != plans[y].K ? plans[x].K < plans[y].K : plans[x].cost > plans[y].cost;
     });
-    int64_t total_tasks = 0;
+    int64_t total_tasks = 0, stream_pairs = 0;
     for (size_t i = 0; i < by_cost.size();) {
         const int K = plans[by_cost[i]].K;
         Bucket bk;
@@ -519,18 +525,35 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             bk.num_stream_tasks = static_cast<int>(st);
             R->any_stream = true;
         }
-        for (size_t j = bucket_first; j < i; ++j) {
-            const RegionPlan& rp = plans[by_cost[j]];
-            const RegionDesc& d = R->descs[bk.desc_begin + (j - bucket_first)];
-            for (int r = 0; r < rp.nr; ++r) {
-                ReadInfo& ri = read_info[rp.read_begin + r];
+        if (bk.stream) {
+            bk.pair_begin = stream_pairs;
+            int read_max = 1;
+            for (size_t j = bucket_first; j < i; ++j) {
+                const RegionPlan& rp = plans[by_cost[j]];
                 const gatk_pairhmm_batch& b = regions[rp.region];
-                if (b.read_offsets[r + 1] == b.read_offsets[r] || !bk.stream) continue;  // zero-length reads have no work item
-                ri.task_base += d.task_begin;
-                ri.num_groups = rp.num_groups;
-                ri.num_haps = rp.nh;
-                ri.bucket = bucket_index;
+                read_max = std::max(read_max, rp.read_max);
+                for (int r = 0; r < rp.nr; ++r) {
+                    if (b.read_offsets[r + 1] == b.read_offsets[r]) continue;  // zero-length reads have no work item
+                    ReadInfo& ri = read_info[rp.read_begin + r];
+                    ri.hap_begin = rp.hap_begin;
+                    ri.num_haps = rp.nh;
+                    ri.bucket = bucket_index;
+                    bk.num_pairs += rp.nh;
+                }
             }
+            // The pair pass picks its own rows per lane: at most 8 (more spills in double), the value that
+            // wastes the fewest lane-rows for the bucket's longest read, the smaller one on a tie (the
+            // pass usually has too few pairs to fill the device, so a short sweep matters more than
+            // instruction count).
+            double best_util = -1.0;
+            for (int k : kRowsPerLaneChoices) {
+                if (k < (read_max + 1 + kWave) / kWave) continue;
+                if (k > 8 && best_util >= 0.0) break;
+                const int lanes = (read_max + 1 + k) / k;
+                const double util = static_cast<double>(kWave / lanes) * (read_max + 2) / (static_cast<double>(kWave) * k);
+                if (util > best_util + 0.02) { best_util = util; bk.pair_rows_per_lane = k; bk.slot_lanes = lanes; }
+            }
+            stream_pairs += bk.num_pairs;
         }
         total_tasks += t;
         R->buckets.push_back(bk);
@@ -624,7 +647,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     if (R->any_stream) {
         HIP_TRY(R->d_hap_stream.ensure(R->hap_stream_entries * sizeof(uint16_t)));
         HIP_TRY(R->d_raw_out.ensure(std::max<size_t>(static_cast<size_t>(call_pairs) * sizeof(float), 16)));
-        HIP_TRY(R->d_rerun_flags.ensure(std::max<size_t>(static_cast<size_t>(total_tasks) * sizeof(int32_t), 16)));
+        HIP_TRY(R->d_pair_lists.ensure(std::max<size_t>(static_cast<size_t>(stream_pairs) * sizeof(RerunPair), 16)));
     }
     if (L.size) HIP_TRY(hipMemcpyAsync(R->d_arena.p, S, L.size, hipMemcpyHostToDevice, s));
     const uint8_t* D = R->d_arena.as<uint8_t>();
@@ -647,8 +670,8 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     B.read_info = reinterpret_cast<const ReadInfo*>(D + o_rinfo);
     B.hap_stream = R->d_hap_stream.as<uint16_t>();
     B.raw_out = R->d_raw_out.as<float>();
-    B.rerun_flags = R->d_rerun_flags.as<int32_t>();
-    for (size_t bi = 0; bi < R->buckets.size(); ++bi) B.bucket_task_begin[bi] = R->buckets[bi].task_begin;
+    B.pair_lists = R->d_pair_lists.as<RerunPair>();
+    for (size_t bi = 0; bi < R->buckets.size(); ++bi) B.bucket_pair_begin[bi] = static_cast<int32_t>(R->buckets[bi].pair_begin);
     B.row_consts = R->d_row_consts.as<RowConst>();
     R->d_neg_inf_idx = reinterpret_cast<const int32_t*>(D + o_neg);
     // the staging buffer is reused by the next upload on this handle: finish the copy first
@@ -658,7 +681,8 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     return GATK_PAIRHMM_OK;
 }
 
-// counters layout: [0] error word, [1 + b] rerun count of bucket b
+// counters layout: [0] error word, [1 + b] rerun-list length of bucket b (one-haplotype passes),
+// [1 + kMaxBuckets + b] pairs queued for the fp64 pair pass of bucket b (stream pass)
 
 int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     HIP_TRY(hipSetDevice(h->device));
@@ -683,13 +707,11 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     B.error_word = R->d_counters.as<int32_t>();
     B.fp32_threshold = h->fp32_threshold;
     HIP_TRY(launch_validate(B, s));
-    B.rerun_counts = R->d_counters.as<int32_t>() + 1;
-    B.rerun_lists = R->d_rerun_lists.as<int32_t>();
+    B.pair_counts = R->d_counters.as<int32_t>() + 1 + kMaxBuckets;
     const bool streaming = R->any_stream && !h->force_fp64;
     if (!h->force_fp64) HIP_TRY(launch_expand_reads(B, s));
     if (streaming) {
         HIP_TRY(hipMemsetAsync(B.hap_stream, 0, R->hap_stream_entries * sizeof(uint16_t), s));
-        HIP_TRY(hipMemsetAsync(B.rerun_flags, 0, std::max<size_t>(static_cast<size_t>(R->total_tasks) * sizeof(int32_t), 16), s));
         HIP_TRY(launch_expand_haps(B, s));
     }
     if (R->num_neg_inf > 0) HIP_TRY(launch_fill_neg_inf(B.out, R->d_neg_inf_idx, R->num_neg_inf, s));
@@ -726,11 +748,21 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     if (!h->force_fp64) {
         for (size_t bi = 0; bi < R->buckets.size(); ++bi) {
             const Bucket& bk = R->buckets[bi];
+            if (streaming && bk.stream) {  // only the pairs that asked for it, repacked
+                DeviceBatch L = B;
+                L.pair_count = B.pair_counts + bi;
+                L.pair_list = B.pair_lists + bk.pair_begin;
+                L.slot_lanes = bk.slot_lanes;
+                const int64_t waves = (bk.num_pairs + kWave / bk.slot_lanes - 1) / (kWave / bk.slot_lanes);
+                HIP_TRY(launch_pairs(L, bk.pair_rows_per_lane, static_cast<int>(std::min<int64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, 2048)), s));
+                continue;
+            }
             const int blocks = std::min((bk.num_tasks + kWavesPerBlock - 1) / kWavesPerBlock, 1024);
             HIP_TRY(launch_forward(bucket_args(bi, bk.emit_mode_fp64), bk.rows_per_lane, bk.emit_mode_fp64, true, true, blocks, s));
         }
     }
     if (timing) HIP_TRY(hipEventRecord(ev[4], s));
+    R->streamed = streaming;
     R->computed = true;
     return GATK_PAIRHMM_OK;
 }
@@ -750,7 +782,7 @@ int group_of_task(const gatk_pairhmm_resident* R, const Bucket& bk, int task) {
 int finish_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(R->stream));
-    int32_t counters[1 + kMaxBuckets] = {0};
+    int32_t counters[1 + 2 * kMaxBuckets] = {0};
     HIP_TRY(hipMemcpy(counters, R->d_counters.p, sizeof counters, hipMemcpyDeviceToHost));
     gatk_pairhmm_stats st{};
     st.pairs = R->total_pairs;
@@ -760,6 +792,13 @@ int finish_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     st.host_upload_ms = R->upload_ms;
     for (size_t bi = 0; bi < R->buckets.size(); ++bi) {
         const Bucket& bk = R->buckets[bi];
+        if (R->streamed && bk.stream) {
+            const int64_t n = std::min<int64_t>(counters[1 + kMaxBuckets + bi], bk.num_pairs);
+            const int per_wave = kWave / bk.slot_lanes;
+            st.rerun_pairs += n;
+            st.rerun_tasks += (n + per_wave - 1) / per_wave;
+            continue;
+        }
         const int n = std::min(counters[1 + bi], bk.num_tasks);
         st.rerun_tasks += n;
         if (n > 0) {

@@ -89,10 +89,16 @@ struct StreamDesc {
 
 // What the pass that turns the stream pass's raw sums into log10 needs to know about a read.
 struct ReadInfo {
-    int32_t task_base;   // single-haplotype work item of (this read's wave-group, haplotype 0), bucket-local
-    int32_t num_groups;  // wave-groups of the read's region: the item of haplotype a is task_base + a * num_groups
+    int32_t hap_begin;   // global index of the first haplotype of the read's region
     int32_t num_haps;    // haplotypes of the read's region; 0: nothing to do for this read
     int32_t bucket;      // launch bucket of the region, or -1 when the stream pass did not score it
+    int32_t reserved;
+};
+
+// A (read, haplotype) pair fp32 could not hold, queued for the fp64 pair pass.
+struct RerunPair {
+    int32_t read_idx;   // global read index
+    int32_t hap_local;  // haplotype index within the read's region
 };
 
 constexpr int kMaxBuckets = 16;  // one bucket per rows-per-lane value in use
@@ -124,10 +130,13 @@ struct DeviceBatch {
     int32_t num_stream_descs;
     float* raw_out;                // [pairs] scaled likelihood sums, laid out like out
     const ReadInfo* read_info;     // [num_reads]
-    int32_t* rerun_flags;          // [work items of all buckets] 1 once an item is on a rerun list
-    int32_t* rerun_counts;         // [kMaxBuckets]
-    int32_t* rerun_lists;          // rerun lists of all buckets, bucket b starting at bucket_task_begin[b]
-    int32_t bucket_task_begin[kMaxBuckets];
+    int32_t* pair_counts;          // [kMaxBuckets] pairs queued for the fp64 pair pass
+    RerunPair* pair_lists;         // their lists, bucket b starting at bucket_pair_begin[b]
+    int32_t bucket_pair_begin[kMaxBuckets];
+    // fp64 pair pass of one bucket
+    const int32_t* pair_count;     // = pair_counts + bucket
+    const RerunPair* pair_list;    // = pair_lists + bucket_pair_begin[bucket]
+    int32_t slot_lanes;            // lanes every pair gets: enough for the bucket's longest read
     int32_t num_region_descs;
     int32_t num_tasks;             // this launch's work items
     const double* err_prob;        // [256]

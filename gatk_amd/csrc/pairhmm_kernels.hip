@@ -726,7 +726,7 @@ __global__ void __launch_bounds__(256) expand_haps(const DeviceBatch B) {
 }
 
 // Raw sums of the stream pass -> log10 likelihoods; pairs fp32 could not hold go on their bucket's
-// rerun list as single-haplotype work items (once each, whichever of the group's reads asks first).
+// list for the fp64 pair pass (one counter update per wave).
 __global__ void __launch_bounds__(256) finish_stream(const DeviceBatch B) {
     const int read = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (read >= B.num_reads) return;
@@ -734,28 +734,156 @@ __global__ void __launch_bounds__(256) finish_stream(const DeviceBatch B) {
     if (info.bucket < 0) return;
     const int ob = B.read_out_base[read];
     const int lane = threadIdx.x & 63;
-    const int list_begin = B.bucket_task_begin[info.bucket];
+    RerunPair* const list = B.pair_lists + B.bucket_pair_begin[info.bucket];
     for (int a0 = 0; a0 < info.num_haps; a0 += kWave) {  // wave-uniform trip count
         const int a = a0 + lane;
         bool push = false;
-        int task = 0;
         if (a < info.num_haps) {
             const float total = B.raw_out[ob + a];
             B.out[ob + a] = ::log10(static_cast<double>(total)) - Scale<float>::kExp2 * 0.30102999566398119521;
-            if (!(total >= B.fp32_threshold && total <= 3.0e38f)) {
-                task = info.task_base + a * info.num_groups;
-                push = atomicExch(&B.rerun_flags[list_begin + task], 1) == 0;
-            }
+            push = !(total >= B.fp32_threshold && total <= 3.0e38f);
         }
-        // one counter update per wave: the first pushing lane reserves room for all of them
         const unsigned long long pushing = __ballot(push);
         if (pushing != 0) {
             const int leader = __ffsll(static_cast<long long>(pushing)) - 1;
             int base = 0;
-            if (lane == leader) base = atomicAdd(&B.rerun_counts[info.bucket], __popcll(pushing));
+            if (lane == leader) base = atomicAdd(&B.pair_counts[info.bucket], __popcll(pushing));
             base = __shfl(base, leader);
-            if (push) B.rerun_lists[list_begin + base + __popcll(pushing & ((1ull << lane) - 1ull))] = task;
+            if (push) list[base + __popcll(pushing & ((1ull << lane) - 1ull))] = RerunPair{read, a};
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp64 pair pass
+// ---------------------------------------------------------------------------------------------
+// Scores the queued (read, haplotype) pairs in double, plain arithmetic form.  A wave takes
+// 64 / slot_lanes consecutive pairs of the list, whatever reads and haplotypes they are: every pair
+// gets slot_lanes lanes, and each lane follows its own haplotype through the code stream.  Only the
+// pairs that need it are recomputed, however they were grouped in the fp32 pass.
+template <int K>
+__device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_pair, const int num_pairs, const int lane) {
+    using T = double;
+    const int slot = lane / B.slot_lanes;
+    const int t = lane - slot * B.slot_lanes;
+    const bool have = slot < num_pairs;
+    RerunPair pr{0, 0};
+    if (have) pr = B.pair_list[first_pair + slot];
+    const int ro = B.read_off[pr.read_idx];
+    const int R = have ? B.read_off[pr.read_idx + 1] - ro : 0;
+    const int seg_lanes = (R + 1 + K) / K;
+    const bool used = have && t < seg_lanes;
+    const int first_row = t * K + 1 - (seg_lanes * K - R - 1);  // pads | rows 1..R | sum row
+    const bool seg_last = t == seg_lanes - 1;
+    const int hap = B.read_info[pr.read_idx].hap_begin + pr.hap_local;
+    const int H = used ? B.hap_len[hap] : 0;
+    const uint16_t* const hp = B.hap_stream + (used ? B.hap_stream_off[hap] : kStreamFrontPad) - t;  // hp[s]: code of column s - t (0-based)
+
+    // per-row constants straight from the quality bytes (as the one-haplotype fp64 pass does)
+    Rows<T, K> w;
+    unsigned XC[K];  // table offset of the read base's code; one that no haplotype entry holds for other letters
+    T P[K], Q[K];
+    const T initD = static_cast<T>(::ldexp(1.0, Scale<T>::kExp2) / static_cast<double>(H > 0 ? H : 1));
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        const int i = first_row + r;
+        double p = 0, q = 0, t4 = 0, t5 = 0, t0n = 0, t1n = 0, t2n = 0, t3n = 0;
+        bool pad = false, has_next = false;
+        unsigned xc = 0xffffu;
+        const bool sum_row = used && i == R + 1;
+        const bool last_row = used && i == R;
+        if (sum_row) {
+            p = q = 1.0;
+            t5 = 1.0;
+        } else if (used) {
+            if (i >= 1) {
+                const unsigned x = B.read_bases[ro + i - 1];
+                const double e = B.err_prob[B.read_quals[ro + i - 1]];
+                xc = (x == 'A' ? 0u : x == 'C' ? 1u : x == 'T' ? 2u : x == 'G' ? 3u : 0x7fu) * kLutCodeStride;
+                p = 1.0 - e;
+                q = (x == 'N') ? p : e / 3.0;
+                t4 = B.err_prob[B.del_gop[ro + i - 1] & 127u];
+                t5 = B.err_prob[B.gcp[ro + i - 1]];
+            } else {
+                pad = true;
+                t4 = 1.0;
+                t5 = 1.0;
+                if (i < 0) t1n = 1.0;
+            }
+            if (i >= 0 && i < R) {
+                const unsigned ins = B.ins_gop[ro + i] & 127u, del = B.del_gop[ro + i] & 127u;
+                const double eg = B.err_prob[B.gcp[ro + i]];
+                has_next = true;
+                t0n = B.match_to_match[ins * 128u + del];
+                t1n = 1.0 - eg;
+                t2n = B.err_prob[ins];
+                t3n = eg;
+            }
+        }
+        const bool real_next = has_next && i >= 1;
+        XC[r] = xc;
+        P[r] = p; Q[r] = q;
+        w.T5[r] = t5;
+        w.A[r] = real_next ? t0n : last_row ? 1.0 : 0.0;
+        w.B[r] = last_row ? 1.0 : t1n;
+        w.C[r] = real_next ? t2n : 0.0;
+        w.D[r] = real_next ? t3n : 0.0;
+        w.E[r] = t4 * t1n;
+        pin(w.A[r]); pin(w.B[r]); pin(w.C[r]); pin(w.D[r]); pin(w.E[r]); pin(w.T5[r]);
+        pin(XC[r]); pin(P[r]); pin(Q[r]);
+        w.Ml[r] = 0.0;
+        w.El[r] = pad ? initD : 0.0;  // column 0
+    }
+#pragma unroll
+    for (int r = 1; r < K; ++r) w.Sd[r] = w.El[r - 1] * w.E[r - 1];
+    w.Sout = w.El[K - 1] * w.E[K - 1];
+    w.Iout = 0.0;
+    w.Sd[0] = shr1(w.Sout);
+    __builtin_amdgcn_wave_barrier();
+
+    // the longest haplotype of the wave sets the number of steps
+    int hmax = H;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) hmax = max(hmax, __shfl_xor(hmax, d));
+    const int steps = hmax + B.slot_lanes - 1;
+    const unsigned n_code = 4u * kLutCodeStride;
+    // a lane whose haplotype is shorter than the wave's longest stops reading the stream behind its own
+    const int last_block = H + t + 8;
+    uint2 codes = load_codes(hp);
+    uint2 next_codes = load_codes(hp + 4);
+    for (int s0 = 0; s0 < steps; s0 += 4) {
+        const uint2 after = load_codes(hp + min(s0 + 8, last_block));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const T Sin = shr1(w.Sout);
+            const T Iin = shr1(w.Iout);
+            const unsigned y = u == 0 ? (codes.x & 0xffffu) : u == 1 ? (codes.x >> 16) : u == 2 ? (codes.y & 0xffffu) : (codes.y >> 16);
+            if (static_cast<unsigned>(s0 + u - t) < static_cast<unsigned>(H)) {
+                T prior[K];
+#pragma unroll
+                for (int r = 0; r < K; ++r) prior[r] = (y == XC[r] || y == n_code) ? P[r] : Q[r];
+                column<T, K>(w, prior, Sin, Iin);
+            }
+        }
+        codes = next_codes;
+        next_codes = after;
+    }
+    if (used && seg_last) {
+        const T total = w.El[K - 1] + w.Ml[K - 1] + w.Sd[K - 1];  // the sum row
+        B.out[B.read_out_base[pr.read_idx] + pr.hap_local] = ::log10(total) - Scale<T>::kExp2 * 0.30102999566398119521;
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_pairs(const DeviceBatch B) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int n = *B.pair_count;
+    const int per_wave = kWave / B.slot_lanes;
+    const int stride = gridDim.x * kWavesPerBlock * per_wave;
+    for (int first = (blockIdx.x * kWavesPerBlock + wave) * per_wave; first < n; first += stride) {
+        run_pairs<K>(B, first, min(per_wave, n - first), lane);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -938,6 +1066,21 @@ hipError_t launch_stream(const DeviceBatch& B, int rows_per_lane, int emit_mode,
         case 16: return launch_stream_k<16>(B, emit_mode, blocks, stream);
         default: return hipErrorInvalidValue;
     }
+}
+
+// Enqueue the fp64 pair pass of one bucket (B.pair_count / pair_list / slot_lanes set for it).
+hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int blocks, hipStream_t stream) {
+    if (blocks <= 0) return hipSuccess;
+    const dim3 grid(blocks), block(kWave * kWavesPerBlock);
+    switch (rows_per_lane) {
+#define PAIRHMM_PAIRS_CASE(k) case k: hipLaunchKernelGGL((fwd_pairs<k>), grid, block, 0, stream, B); break;
+        PAIRHMM_PAIRS_CASE(1) PAIRHMM_PAIRS_CASE(2) PAIRHMM_PAIRS_CASE(3) PAIRHMM_PAIRS_CASE(4) PAIRHMM_PAIRS_CASE(5)
+        PAIRHMM_PAIRS_CASE(6) PAIRHMM_PAIRS_CASE(7) PAIRHMM_PAIRS_CASE(8) PAIRHMM_PAIRS_CASE(9) PAIRHMM_PAIRS_CASE(10)
+        PAIRHMM_PAIRS_CASE(11) PAIRHMM_PAIRS_CASE(12) PAIRHMM_PAIRS_CASE(14) PAIRHMM_PAIRS_CASE(16)
+#undef PAIRHMM_PAIRS_CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_expand_haps(const DeviceBatch& B, hipStream_t stream) {

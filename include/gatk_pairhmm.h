@@ -63,8 +63,8 @@ typedef struct gatk_pairhmm_stats {
     int64_t pairs;          /* (read, haplotype) pairs scored */
     int64_t cells;          /* sum of readLen * hapLen over those pairs */
     int64_t wave_tasks;     /* wavefront work items launched in fp32 */
-    int64_t rerun_tasks;    /* of those, recomputed in fp64 because a pair fell under the fp32 threshold */
-    int64_t rerun_pairs;    /* pairs covered by the recomputed work items */
+    int64_t rerun_tasks;    /* wavefront work items of the fp64 pass */
+    int64_t rerun_pairs;    /* pairs recomputed in fp64 because their fp32 sum fell under the threshold */
     double fp32_kernel_ms;  /* device time of the fp32 forward kernels (HIP events), 0 if not timed */
     double fp64_kernel_ms;  /* device time of the fp64 rerun kernels (HIP events), 0 if not timed */
     double host_plan_ms;    /* host time spent checking, planning and packing the call */

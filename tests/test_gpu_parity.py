@@ -90,7 +90,7 @@ def test_threshold_sweep(hmm, oracle):
     try:
         hmm.set_option("fp32_threshold", 3e38)
         all64 = hmm.compute_batch(b)
-        assert hmm.stats()["rerun_tasks"] == hmm.stats()["wave_tasks"]
+        assert hmm.stats()["rerun_pairs"] == hmm.stats()["pairs"]
         assert_parity(all64, want, tol=1e-9)
         hmm.set_option("fp32_threshold", 1e-28)
         default = hmm.compute_batch(b)
@@ -425,16 +425,37 @@ def test_runs_with_haplotypes_shorter_than_the_pipeline(hmm, oracle, k):
     assert_parity(got, want)
 
 
-def test_runs_requeue_underflowing_pairs_once(hmm, oracle):
-    # half the haplotypes are unrelated to the reads: their pairs underflow fp32 and go through the
-    # fp64 pass as single-haplotype items, whichever run they were scored in
+def test_only_underflowing_pairs_go_through_the_fp64_pair_pass(hmm, oracle):
     b = synth.config_c5(num_reads=96, num_haps=12)
     want = ref(oracle, b)
     got = hmm.compute_batch(b)
     assert_parity(got, want)
     st = hmm.stats()
-    assert 0 < st["rerun_pairs"] <= st["pairs"]
-    assert st["rerun_tasks"] <= st["wave_tasks"]
+    assert 0 < st["rerun_pairs"] < st["pairs"]
+    # the one-haplotype passes queue whole wave-groups: more pairs recomputed for the same result
+    single = with_options(hmm, {"stream_mode": 0}, lambda: (hmm.compute_batch(b), hmm.stats()))
+    np.testing.assert_allclose(single[0], got, rtol=0, atol=1e-6)
+    assert st["rerun_pairs"] <= single[1]["rerun_pairs"]
+    # the pair pass is exact to the oracle where it ran: force it everywhere
+    hmm.set_option("fp32_threshold", 3e38)
+    try:
+        assert_parity(hmm.compute_batch(b), want, tol=1e-9)
+    finally:
+        hmm.set_option("fp32_threshold", 1e-28)
+
+
+def test_fp64_pair_pass_with_ragged_reads_and_haplotypes(hmm, oracle):
+    # every pair through the pair pass: reads of 1..300 bases share waves, haplotypes of 20..700 bases
+    b = synth.make_batch(70, 9, 300, 360, seed=41, len_jitter=299, hap_len_jitter=340, gop_model="random")
+    want = ref(oracle, b)
+    hmm.set_option("fp32_threshold", 3e38)
+    try:
+        for k in (0, 5, 16):
+            got = with_options(hmm, {"force_rows_per_lane": k}, lambda: hmm.compute_batch(b))
+            assert hmm.stats()["rerun_pairs"] == b.num_reads * b.num_haps
+            assert_parity(got, want, tol=1e-9)
+    finally:
+        hmm.set_option("fp32_threshold", 1e-28)
 
 
 def test_runs_across_regions_with_n_in_haplotypes(hmm, oracle):
