@@ -32,6 +32,10 @@ hipError_t launch_stream(const DeviceBatch& B, int rows_per_lane, int emit_mode,
 hipError_t launch_expand_haps(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_finish_stream(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int blocks, hipStream_t stream);
+hipError_t launch_normalize_reads(const DeviceBatch& B, const int32_t* reference_allele_index, int best_to_zero, double cap, hipStream_t stream);
+hipError_t launch_flag_poorly_modelled_reads(const DeviceBatch& B, double maximum_error_per_base, uint8_t* flags, hipStream_t stream);
+hipError_t launch_marginalize_reads(const DeviceBatch& B, const int32_t* old_to_new, const int64_t* new_base, const int32_t* new_count,
+                                    double* new_out, hipStream_t stream);
 hipError_t launch_validate(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_expand_reads(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_fill_neg_inf(double* out, const int32_t* idx, int n, hipStream_t stream);
@@ -140,6 +144,10 @@ struct gatk_pairhmm_resident {
     DevBuf d_row_consts;  // fp32 row constants of every read, written on the device
     DevBuf d_hap_stream, d_raw_out, d_pair_lists;  // fp32 stream pass and the fp64 pair pass behind it
     size_t hap_stream_entries = 0;
+    std::vector<int32_t> region_reads, region_haps;     // per region of the call (0 haplotypes when it has no reads)
+    std::vector<int32_t> region_read_begin, region_hap_begin;  // global index of a region's first read / haplotype
+    int64_t total_reads = 0, total_haps = 0;
+    DevBuf d_epilogue;  // small arrays of the steps behind the path: per-region parameters, flags, marginal likelihoods
     bool any_stream = false;
     bool streamed = false;  // the last pass enqueued used the stream pass and the fp64 pair pass
     DeviceBatch base{};  // pointers into d_arena
@@ -150,7 +158,7 @@ struct gatk_pairhmm_resident {
     std::vector<EventSet> ev_pending, ev_free;
     gatk_pairhmm_stats last_timing{};
     void release() {
-        for (DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_counters, &d_row_consts, &d_hap_stream, &d_raw_out, &d_pair_lists}) b->release();
+        for (DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_counters, &d_row_consts, &d_hap_stream, &d_raw_out, &d_pair_lists, &d_epilogue}) b->release();
         for (auto* v : {&ev_pending, &ev_free}) {
             for (auto& set : *v)
                 for (auto& e : set)
@@ -379,7 +387,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     segs.reserve(static_cast<size_t>(total_reads));
     std::vector<int32_t> neg_inf_idx;
     std::vector<int> order, lens_desc;
-    std::vector<ReadInfo> read_info(static_cast<size_t>(total_reads), ReadInfo{0, 0, -1, 0});
+    std::vector<ReadInfo> read_info(static_cast<size_t>(total_reads));
     std::vector<StreamDesc> stream_descs;
     bool any_hap_n = false, any_hap_other = false;
     int64_t cells = 0;
@@ -413,6 +421,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         }
         read_max_all = std::max(read_max_all, read_max);
         rp.read_max = read_max;
+        for (int r = 0; r < nr; ++r) read_info[rp.read_begin + r] = ReadInfo{rp.hap_begin, nh, -1, k};
         // wave-groups: longest reads first, filled lane segment by lane segment up to 64 lanes
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
             return (b.read_offsets[x + 1] - b.read_offsets[x]) > (b.read_offsets[y + 1] - b.read_offsets[y]);
@@ -534,10 +543,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
                 read_max = std::max(read_max, rp.read_max);
                 for (int r = 0; r < rp.nr; ++r) {
                     if (b.read_offsets[r + 1] == b.read_offsets[r]) continue;  // zero-length reads have no work item
-                    ReadInfo& ri = read_info[rp.read_begin + r];
-                    ri.hap_begin = rp.hap_begin;
-                    ri.num_haps = rp.nh;
-                    ri.bucket = bucket_index;
+                    read_info[rp.read_begin + r].bucket = bucket_index;
                     bk.num_pairs += rp.nh;
                 }
             }
@@ -559,6 +565,20 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         R->buckets.push_back(bk);
     }
     R->total_pairs = call_pairs;
+    R->total_reads = total_reads;
+    R->total_haps = total_haps;
+    R->region_reads.assign(num_regions, 0); R->region_haps.assign(num_regions, 0);
+    R->region_read_begin.assign(num_regions, 0); R->region_hap_begin.assign(num_regions, 0);
+    {
+        int rb = 0, hb = 0;
+        for (int k = 0; k < num_regions; ++k) {
+            const int nr = regions[k].num_reads, nh = nr == 0 ? 0 : regions[k].num_haps;
+            R->region_read_begin[k] = rb; R->region_hap_begin[k] = hb;
+            if (nr == 0 || nh == 0) continue;
+            R->region_reads[k] = nr; R->region_haps[k] = nh;
+            rb += nr; hb += nh;
+        }
+    }
     R->cells = cells;
     R->total_tasks = total_tasks;
     R->total_read_bytes = total_read_bytes;
@@ -1218,6 +1238,115 @@ int gatk_pairhmm_get_stream(gatk_pairhmm* h, void** stream) {
     if (int rc = check_handle(h)) return rc;
     if (!stream) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "stream cannot be null");
     *stream = h->stream;
+    return GATK_PAIRHMM_OK;
+}
+
+// ---- the steps right behind the path, on results still on the device -----------------------------
+
+namespace {
+int check_epilogue(gatk_pairhmm* h, gatk_pairhmm_resident* r) {
+    if (int rc = check_handle(h)) return rc;
+    if (!r) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "resident batch cannot be null");
+    if (r->total_pairs > 0 && !r->computed) return fail(GATK_PAIRHMM_ILLEGAL_STATE, "likelihoods have not been computed yet");
+    return GATK_PAIRHMM_OK;
+}
+DeviceBatch epilogue_batch(gatk_pairhmm_resident* r) {
+    DeviceBatch B = r->base;
+    B.out = r->d_out.as<double>();
+    return B;
+}
+}  // namespace
+
+int gatk_pairhmm_normalize_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, const int32_t* reference_allele_index,
+                                    int32_t best_to_zero, double maximum_likelihood_difference_cap) {
+    if (int rc = check_epilogue(h, r)) return rc;
+    const double cap = maximum_likelihood_difference_cap;
+    if (cap >= 0.0 || std::isnan(cap)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "the minimum reference likelihood fall cannot be positive");
+    if (cap == -std::numeric_limits<double>::infinity() && !best_to_zero) return GATK_PAIRHMM_OK;  // ReadLikelihoods.java:357-358
+    if (r->total_pairs == 0) return GATK_PAIRHMM_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    const int32_t* d_ref = nullptr;
+    if (reference_allele_index) {
+        for (int k = 0; k < r->num_regions; ++k)
+            if (r->region_haps[k] > 0 && (reference_allele_index[k] < -1 || reference_allele_index[k] >= r->region_haps[k]))
+                return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "reference allele index out of range (region " + std::to_string(k) + ")");
+        HIP_TRY(r->d_epilogue.ensure(static_cast<size_t>(r->num_regions) * sizeof(int32_t)));
+        HIP_TRY(hipStreamSynchronize(r->stream));  // the buffer may still be in use by an earlier step
+        HIP_TRY(hipMemcpyAsync(r->d_epilogue.p, reference_allele_index, static_cast<size_t>(r->num_regions) * sizeof(int32_t), hipMemcpyHostToDevice, r->stream));
+        d_ref = r->d_epilogue.as<int32_t>();
+    }
+    HIP_TRY(launch_normalize_reads(epilogue_batch(r), d_ref, best_to_zero ? 1 : 0, cap, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));  // reference_allele_index is the caller's memory
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_poorly_modeled_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, double maximum_error_per_base, uint8_t* const* flags) {
+    if (int rc = check_epilogue(h, r)) return rc;
+    if (std::isnan(maximum_error_per_base) || maximum_error_per_base <= 0.0)
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "the maximum error per base must be a positive number");
+    if (r->total_pairs == 0) return GATK_PAIRHMM_OK;
+    if (!flags) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "flags cannot be null");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(r->d_epilogue.ensure(static_cast<size_t>(r->total_reads)));
+    HIP_TRY(launch_flag_poorly_modelled_reads(epilogue_batch(r), maximum_error_per_base, r->d_epilogue.as<uint8_t>(), r->stream));
+    std::vector<uint8_t> host(static_cast<size_t>(r->total_reads));
+    HIP_TRY(hipMemcpyAsync(host.data(), r->d_epilogue.p, host.size(), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    for (int k = 0; k < r->num_regions; ++k) {
+        if (r->region_haps[k] == 0) continue;
+        if (!flags[k]) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "flags cannot be null (region " + std::to_string(k) + ")");
+        memcpy(flags[k], host.data() + r->region_read_begin[k], static_cast<size_t>(r->region_reads[k]));
+    }
+    return GATK_PAIRHMM_OK;
+}
+
+int gatk_pairhmm_marginalize_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, const int32_t* const* old_to_new_allele_index,
+                                      const int32_t* new_allele_count, double* const* new_likelihoods) {
+    if (int rc = check_epilogue(h, r)) return rc;
+    if (r->total_pairs == 0) return GATK_PAIRHMM_OK;
+    if (!old_to_new_allele_index || !new_allele_count || !new_likelihoods) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "argument cannot be null");
+    // one upload: [map per global haplotype][new count per region][new row offset per read]
+    std::vector<int32_t> map(static_cast<size_t>(r->total_haps)), counts(static_cast<size_t>(r->num_regions), 0);
+    std::vector<int64_t> base(static_cast<size_t>(r->total_reads));
+    std::vector<int64_t> region_new_off(static_cast<size_t>(r->num_regions) + 1, 0);
+    for (int k = 0; k < r->num_regions; ++k) {
+        region_new_off[k + 1] = region_new_off[k];
+        if (r->region_haps[k] == 0) continue;
+        const int n_new = new_allele_count[k];
+        if (n_new < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "negative allele count (region " + std::to_string(k) + ")");
+        if (!old_to_new_allele_index[k] || (!new_likelihoods[k] && n_new > 0))
+            return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "argument cannot be null (region " + std::to_string(k) + ")");
+        counts[k] = n_new;
+        for (int a = 0; a < r->region_haps[k]; ++a) {
+            const int n = old_to_new_allele_index[k][a];
+            if (n < -1 || n >= n_new) return fail(GATK_PAIRHMM_INDEX_OUT_OF_BOUNDS, "new allele index out of range (region " + std::to_string(k) + ")");
+            map[r->region_hap_begin[k] + a] = n;
+        }
+        for (int x = 0; x < r->region_reads[k]; ++x) base[r->region_read_begin[k] + x] = region_new_off[k] + static_cast<int64_t>(x) * n_new;
+        region_new_off[k + 1] += static_cast<int64_t>(r->region_reads[k]) * n_new;
+    }
+    const int64_t total_new = region_new_off[r->num_regions];
+    if (total_new == 0) return GATK_PAIRHMM_OK;
+    HIP_TRY(hipSetDevice(h->device));
+    ArenaLayout L;
+    const size_t o_base = L.add(base.size() * sizeof(int64_t)), o_map = L.add(map.size() * sizeof(int32_t)),
+                 o_counts = L.add(counts.size() * sizeof(int32_t)), o_out = L.add(static_cast<size_t>(total_new) * sizeof(double));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(r->d_epilogue.ensure(L.size));
+    uint8_t* D = r->d_epilogue.as<uint8_t>();
+    HIP_TRY(hipMemcpyAsync(D + o_base, base.data(), base.size() * sizeof(int64_t), hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipMemcpyAsync(D + o_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipMemcpyAsync(D + o_counts, counts.data(), counts.size() * sizeof(int32_t), hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(launch_marginalize_reads(epilogue_batch(r), reinterpret_cast<const int32_t*>(D + o_map), reinterpret_cast<const int64_t*>(D + o_base),
+                                     reinterpret_cast<const int32_t*>(D + o_counts), reinterpret_cast<double*>(D + o_out), r->stream));
+    std::vector<double> host(static_cast<size_t>(total_new));
+    HIP_TRY(hipMemcpyAsync(host.data(), D + o_out, host.size() * sizeof(double), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    for (int k = 0; k < r->num_regions; ++k) {
+        const int64_t n = region_new_off[k + 1] - region_new_off[k];
+        if (n > 0) memcpy(new_likelihoods[k], host.data() + region_new_off[k], static_cast<size_t>(n) * sizeof(double));
+    }
     return GATK_PAIRHMM_OK;
 }
 

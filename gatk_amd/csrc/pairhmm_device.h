@@ -90,9 +90,9 @@ struct StreamDesc {
 // What the pass that turns the stream pass's raw sums into log10 needs to know about a read.
 struct ReadInfo {
     int32_t hap_begin;   // global index of the first haplotype of the read's region
-    int32_t num_haps;    // haplotypes of the read's region; 0: nothing to do for this read
-    int32_t bucket;      // launch bucket of the region, or -1 when the stream pass did not score it
-    int32_t reserved;
+    int32_t num_haps;    // haplotypes of the read's region
+    int32_t bucket;      // launch bucket of the region, or -1 when the stream pass did not score the read
+    int32_t region;      // index of the read's region among the call's regions
 };
 
 // A (read, haplotype) pair fp32 could not hold, queued for the fp64 pair pass.

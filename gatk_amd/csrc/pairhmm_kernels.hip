@@ -887,6 +887,78 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_pairs(const DeviceB
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The steps right behind the path (genotyper/ReadLikelihoods.java), on the results still on the device.
+// out is read-major: a read's likelihoods against its region's alleles are consecutive.  One thread per read.
+// ---------------------------------------------------------------------------------------------
+
+// ReadLikelihoods.normalizeLikelihoodsPerRead, :375-403 (best alternative allele: :454-484 with
+// canBeReference = false; there is no <NON_REF> allele on this path).
+__global__ void __launch_bounds__(256) normalize_reads(const DeviceBatch B, const int32_t* reference_allele_index, const int best_to_zero,
+                                                       const double cap) {
+    const int read = blockIdx.x * blockDim.x + threadIdx.x;
+    if (read >= B.num_reads) return;
+    const ReadInfo info = B.read_info[read];
+    const int A = info.num_haps;
+    if (A == 0 || (A == 1 && !best_to_zero)) return;  // :361-364
+    const int ref = reference_allele_index ? reference_allele_index[info.region] : -1;
+    double* const v = B.out + B.read_out_base[read];
+    double best_alt = -__builtin_inf();
+    if (!(A == 1 && ref == 0)) {
+        int first = ref != 0 ? 0 : 1;
+        best_alt = v[first];
+        for (int a = first + 1; a < A; ++a)
+            if (a != ref && v[a] > best_alt) best_alt = v[a];
+    }
+    const double worst_cap = best_alt + cap;
+    const double ref_lk = ref == -1 ? -__builtin_inf() : v[ref];
+    const double best_abs = best_alt > ref_lk ? best_alt : ref_lk;
+    for (int a = 0; a < A; ++a) {
+        double x = v[a];
+        if (best_to_zero) {
+            if (best_abs == -__builtin_inf()) x = 0.0;
+            else if (worst_cap != -__builtin_inf()) x = (x < worst_cap ? worst_cap : x) - best_abs;
+            else x -= best_abs;
+        } else if (x < worst_cap) {
+            x = worst_cap;
+        }
+        v[a] = x;
+    }
+}
+
+// ReadLikelihoods.readIsPoorlyModelled, :1081-1093: 1 for the reads filterPoorlyModeledReads removes.
+__global__ void __launch_bounds__(256) flag_poorly_modelled_reads(const DeviceBatch B, const double maximum_error_per_base, uint8_t* flags) {
+    const int read = blockIdx.x * blockDim.x + threadIdx.x;
+    if (read >= B.num_reads) return;
+    const ReadInfo info = B.read_info[read];
+    const int len = B.read_off[read + 1] - B.read_off[read];
+    const double max_errors = ::fmin(2.0, ::ceil(len * maximum_error_per_base));
+    const double threshold = max_errors * -4.0;
+    const double* const v = B.out + B.read_out_base[read];
+    uint8_t poorly = 1;
+    for (int a = 0; a < info.num_haps; ++a)
+        if (v[a] >= threshold) poorly = 0;
+    flags[read] = poorly;
+}
+
+// ReadLikelihoods.marginalLikelihoods, :911-939, keeping every read.  old_to_new[global haplotype]: new
+// allele index within the region or -1; new_base[read]: where the read's new row starts in new_out;
+// new_count[region]: new alleles of the region.
+__global__ void __launch_bounds__(256) marginalize_reads(const DeviceBatch B, const int32_t* old_to_new, const int64_t* new_base,
+                                                         const int32_t* new_count, double* new_out) {
+    const int read = blockIdx.x * blockDim.x + threadIdx.x;
+    if (read >= B.num_reads) return;
+    const ReadInfo info = B.read_info[read];
+    double* const dst = new_out + new_base[read];
+    const int n_new = new_count[info.region];
+    for (int n = 0; n < n_new; ++n) dst[n] = -__builtin_inf();
+    const double* const v = B.out + B.read_out_base[read];
+    for (int a = 0; a < info.num_haps; ++a) {
+        const int n = old_to_new[info.hap_begin + a];
+        if (n >= 0 && v[a] > dst[n]) dst[n] = v[a];
+    }
+}
+
 // One task per wave, tasks taken in launch order.
 template <typename T, int K, int MODE>
 __global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_direct(const DeviceBatch B) {
@@ -1080,6 +1152,25 @@ hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int blocks, hip
 #undef PAIRHMM_PAIRS_CASE
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_normalize_reads(const DeviceBatch& B, const int32_t* reference_allele_index, int best_to_zero, double cap, hipStream_t stream) {
+    if (B.num_reads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(normalize_reads, dim3((B.num_reads + 255) / 256), dim3(256), 0, stream, B, reference_allele_index, best_to_zero, cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_flag_poorly_modelled_reads(const DeviceBatch& B, double maximum_error_per_base, uint8_t* flags, hipStream_t stream) {
+    if (B.num_reads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(flag_poorly_modelled_reads, dim3((B.num_reads + 255) / 256), dim3(256), 0, stream, B, maximum_error_per_base, flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_marginalize_reads(const DeviceBatch& B, const int32_t* old_to_new, const int64_t* new_base, const int32_t* new_count,
+                                    double* new_out, hipStream_t stream) {
+    if (B.num_reads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(marginalize_reads, dim3((B.num_reads + 255) / 256), dim3(256), 0, stream, B, old_to_new, new_base, new_count, new_out);
     return hipGetLastError();
 }
 

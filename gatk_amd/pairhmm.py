@@ -70,7 +70,8 @@ EXPORTS = [
     "gatk_pairhmm_get_stats", "gatk_pairhmm_last_error", "gatk_pairhmm_version", "gatk_pairhmm_device_count",
     "gatk_pairhmm_set_option", "gatk_pairhmm_upload", "gatk_pairhmm_compute_resident", "gatk_pairhmm_download",
     "gatk_pairhmm_resident_free", "gatk_pairhmm_get_stream", "gatk_pairhmm_resident_device_output",
-    "gatk_pairhmm_wait_resident",
+    "gatk_pairhmm_wait_resident", "gatk_pairhmm_normalize_resident", "gatk_pairhmm_poorly_modeled_resident",
+    "gatk_pairhmm_marginalize_resident",
 ]
 
 _lib = None
@@ -97,6 +98,9 @@ def load_library():
         L.gatk_pairhmm_download.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.gatk_pairhmm_resident_free.argtypes = [C.c_void_p, C.c_void_p]
         L.gatk_pairhmm_wait_resident.argtypes = [C.c_void_p, C.c_void_p]
+        L.gatk_pairhmm_normalize_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double]
+        L.gatk_pairhmm_poorly_modeled_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.POINTER(C.c_void_p)]
+        L.gatk_pairhmm_marginalize_resident.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_void_p)]
         L.gatk_pairhmm_get_stats.argtypes = [C.c_void_p, C.POINTER(CStats)]
         L.gatk_pairhmm_close.argtypes = [C.c_void_p]
         L.gatk_pairhmm_finalize_region.argtypes = [C.c_void_p]
@@ -184,6 +188,32 @@ class Resident:
         arr = (C.c_void_p * max(1, len(outs)))(*[o.ctypes.data if o.size else None for o in outs])
         _check(load_library().gatk_pairhmm_download(self.hmm._h, self.handle, arr))
         return [o.reshape(nr, nh) for o, (nr, nh) in zip(outs, self.shapes)]
+
+    # -- the steps right behind the path (genotyper/ReadLikelihoods.java), on the device results --
+    def normalizeLikelihoods(self, bestToZero, maximumLikelihoodDifferenceCap, referenceAlleleIndex=None):
+        """ReadLikelihoods.normalizeLikelihoods (:353) on every region, in place; referenceAlleleIndex: one
+        index per region (-1: none), or None for no reference allele anywhere."""
+        ref = None if referenceAlleleIndex is None else np.ascontiguousarray(referenceAlleleIndex, dtype=np.int32)
+        assert ref is None or len(ref) == len(self.shapes)
+        _check(load_library().gatk_pairhmm_normalize_resident(self.hmm._h, self.handle, None if ref is None else ref.ctypes.data,
+                                                              1 if bestToZero else 0, maximumLikelihoodDifferenceCap))
+
+    def poorlyModeledReads(self, maximumErrorPerBase):
+        """Per region, uint8 flags of the reads ReadLikelihoods.filterPoorlyModeledReads (:1059) removes."""
+        flags = [np.zeros(nr if nh else 0, dtype=np.uint8) for nr, nh in self.shapes]
+        arr = (C.c_void_p * max(1, len(flags)))(*[f.ctypes.data if f.size else None for f in flags])
+        _check(load_library().gatk_pairhmm_poorly_modeled_resident(self.hmm._h, self.handle, maximumErrorPerBase, arr))
+        return flags
+
+    def marginalize(self, oldToNewAlleleIndexMaps, newAlleleCounts):
+        """ReadLikelihoods.marginalLikelihoods (:911) keeping every read: per region a [reads, new alleles] array."""
+        maps = [np.ascontiguousarray(m, dtype=np.int32) for m in oldToNewAlleleIndexMaps]
+        counts = np.ascontiguousarray(newAlleleCounts, dtype=np.int32)
+        outs = [np.empty((nr if nh else 0, int(c)), dtype=np.float64) for (nr, nh), c in zip(self.shapes, counts)]
+        marr = (C.c_void_p * max(1, len(maps)))(*[m.ctypes.data if m.size else None for m in maps])
+        oarr = (C.c_void_p * max(1, len(outs)))(*[o.ctypes.data if o.size else None for o in outs])
+        _check(load_library().gatk_pairhmm_marginalize_resident(self.hmm._h, self.handle, marr, counts.ctypes.data, oarr))
+        return outs
 
     def device_output(self):
         p, n = C.c_void_p(), C.c_int64()

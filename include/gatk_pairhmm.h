@@ -169,6 +169,28 @@ int gatk_pairhmm_download(gatk_pairhmm* h, gatk_pairhmm_resident* r, double* con
 int gatk_pairhmm_resident_free(gatk_pairhmm* h, gatk_pairhmm_resident* r);
 /* The HIP stream (hipStream_t) the handle enqueues on, for callers that time it with events. */
 int gatk_pairhmm_get_stream(gatk_pairhmm* h, void** stream);
+/*
+ * The steps right behind the path, applied to the likelihoods of a resident batch while they are still on
+ * the device (after compute_resident, before or after download).  Matrices are per region; the engine's
+ * layout is read-major (values[r * alleles + a]), the Java's is values[a][r].  There is no <NON_REF>
+ * allele on this path.
+ *
+ * normalize      : ReadLikelihoods.normalizeLikelihoods(bestToZero, cap), genotyper/ReadLikelihoods.java:353-404,
+ *                  in place; reference_allele_index[k] is region k's reference allele or -1 (NULL: -1
+ *                  everywhere).  IllegalArgumentException for a cap that is not negative.
+ * poorly_modeled : flags[k][r] = 1 for the reads ReadLikelihoods.filterPoorlyModeledReads(maximumErrorPerBase)
+ *                  removes, :1059-1093 (the reads stay in the batch: dropping them is the caller's bookkeeping).
+ * marginalize    : ReadLikelihoods.marginalLikelihoods keeping every read, :911-939:
+ *                  new_likelihoods[k][r * new_allele_count[k] + n] = max over the region's alleles a with
+ *                  old_to_new_allele_index[k][a] == n (-1: allele dropped), -infinity when there is none.
+ */
+int gatk_pairhmm_normalize_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, const int32_t* reference_allele_index,
+                                    int32_t best_to_zero, double maximum_likelihood_difference_cap);
+int gatk_pairhmm_poorly_modeled_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, double maximum_error_per_base,
+                                         uint8_t* const* flags);
+int gatk_pairhmm_marginalize_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, const int32_t* const* old_to_new_allele_index,
+                                      const int32_t* new_allele_count, double* const* new_likelihoods);
+
 /* Device pointer to the resident likelihood array (all regions concatenated, region-major). */
 int gatk_pairhmm_resident_device_output(gatk_pairhmm_resident* r, void** device_ptr, int64_t* count);
 

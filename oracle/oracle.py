@@ -55,6 +55,12 @@ def lib():
         L.oracle_qualToTransProbs.restype = C.c_int
         L.oracle_qualToTransProbsLog10.argtypes = [f64p, C.c_uint8, C.c_uint8, C.c_uint8]
         L.oracle_qualToTransProbsLog10.restype = C.c_int
+        L.oracle_normalizeLikelihoods.argtypes = [f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
+        L.oracle_normalizeLikelihoods.restype = C.c_int
+        L.oracle_poorlyModelledReads.argtypes = [f64p, C.c_int, C.c_int, i32p, C.c_double, u8p]
+        L.oracle_poorlyModelledReads.restype = C.c_int
+        L.oracle_marginalLikelihoods.argtypes = [f64p, C.c_int, C.c_int, C.c_int, i32p, f64p]
+        L.oracle_marginalLikelihoods.restype = None
         L.simd_pairhmm_batch.argtypes = [C.c_int, C.c_int, u8p, u8p, u8p, u8p, u8p, i32p, u8p, i32p, f64p, C.c_int, C.POINTER(C.c_int64)]
         L.simd_pairhmm_batch.restype = C.c_int
         L.simd_pairhmm_isa.restype = C.c_char_p
@@ -119,3 +125,36 @@ def simd_compute_likelihoods(batch, threads=1):
 
 def simd_isa():
     return lib().simd_pairhmm_isa().decode()
+
+
+# ---- downstream of the path (genotyper/ReadLikelihoods.java); matrices are values[allele][read] as in the Java ----
+
+def normalize_likelihoods(values, reference_allele_index, best_to_zero, cap):
+    """ReadLikelihoods.normalizeLikelihoods on one sample's matrix.  Returns (rc, new matrix)."""
+    v = np.array(values, dtype=np.float64, order="C")
+    a, r = v.shape
+    rc = lib().oracle_normalizeLikelihoods(v.ctypes.data_as(C.POINTER(C.c_double)), a, r, reference_allele_index, 1 if best_to_zero else 0, cap)
+    return rc, v
+
+
+def poorly_modelled_reads(values, read_lengths, maximum_error_per_base):
+    """Flags of the reads ReadLikelihoods.filterPoorlyModeledReads removes.  Returns (rc, uint8[reads])."""
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    a, r = v.shape
+    rl = np.ascontiguousarray(read_lengths, dtype=np.int32)
+    out = np.zeros(r, dtype=np.uint8)
+    rc = lib().oracle_poorlyModelledReads(v.ctypes.data_as(C.POINTER(C.c_double)), a, r, rl.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          maximum_error_per_base, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return rc, out
+
+
+def marginal_likelihoods(values, old_to_new, new_allele_count):
+    """ReadLikelihoods.marginalLikelihoods keeping every read.  Returns the new values[allele][read]."""
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    a, r = v.shape
+    m = np.ascontiguousarray(old_to_new, dtype=np.int32)
+    assert len(m) == a
+    out = np.empty((new_allele_count, r), dtype=np.float64)
+    lib().oracle_marginalLikelihoods(v.ctypes.data_as(C.POINTER(C.c_double)), a, new_allele_count, r, m.ctypes.data_as(C.POINTER(C.c_int32)),
+                                     out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out

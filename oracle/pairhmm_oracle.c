@@ -491,3 +491,80 @@ int oracle_logless_batch_fast(int numReads, int numHaps,
 /* Table accessors for tests */
 double oracle_jacobian_entry(int k) { oracle_init(); return jacobianCache[k]; }
 double oracle_mm_table_entry(int idx, int log10form) { oracle_init(); return log10form ? matchToMatchLog10Tab[idx] : matchToMatchProbTab[idx]; }
+
+/* ----------------------------------------------------------------------------------
+ * Downstream of the path: genotyper/ReadLikelihoods.java, one sample.
+ * values is the Java layout, values[a * readCount + r] = sampleValues[a][r].
+ * nonRefAlleleIndex is -1 throughout (no <NON_REF> allele is added on this path).
+ * ---------------------------------------------------------------------------------- */
+
+/* ReadLikelihoods.java:454-484 with canBeReference = false and every allele considered:
+ * the best likelihood among the non-reference alleles, -inf when there is none. */
+static double bestAlternativeLikelihood(const double *values, int alleleCount, int readCount, int referenceAlleleIndex, int r) {
+    if (alleleCount == 0 || (alleleCount == 1 && referenceAlleleIndex == 0)) return -INFINITY;  /* :457-458 */
+    int best = referenceAlleleIndex != 0 ? 0 : 1;                                                /* :461 */
+    double bestLikelihood = values[(size_t)best * readCount + r];
+    for (int a = best + 1; a < alleleCount; a++) {
+        if (referenceAlleleIndex == a) continue;                                                 /* :466-467 */
+        const double c = values[(size_t)a * readCount + r];
+        if (c > bestLikelihood) bestLikelihood = c;                                              /* :473-477 */
+    }
+    return bestLikelihood;
+}
+
+/* ReadLikelihoods.normalizeLikelihoods, :353-404.  Returns ORACLE_ILLEGAL_ARGUMENT for a cap that
+ * is not negative (:354-355). */
+int oracle_normalizeLikelihoods(double *values, int alleleCount, int readCount, int referenceAlleleIndex,
+                                int bestToZero, double maximumLikelihoodDifferenceCap) {
+    if (maximumLikelihoodDifferenceCap >= 0.0 || isnan(maximumLikelihoodDifferenceCap)) return ORACLE_ILLEGAL_ARGUMENT;
+    if (maximumLikelihoodDifferenceCap == -INFINITY && !bestToZero) return ORACLE_OK;            /* :357-358 */
+    if (alleleCount == 0) return ORACLE_OK;                                                      /* :361-362 */
+    if (alleleCount == 1 && !bestToZero) return ORACLE_OK;                                       /* :363-364 */
+    for (int r = 0; r < readCount; r++) {                                                        /* :375-403 */
+        const double bestAlt = bestAlternativeLikelihood(values, alleleCount, readCount, referenceAlleleIndex, r);
+        const double worstLikelihoodCap = bestAlt + maximumLikelihoodDifferenceCap;
+        const double referenceLikelihood = referenceAlleleIndex == -1 ? -INFINITY : values[(size_t)referenceAlleleIndex * readCount + r];
+        const double bestAbsoluteLikelihood = bestAlt > referenceLikelihood ? bestAlt : referenceLikelihood;  /* Math.max */
+        for (int a = 0; a < alleleCount; a++) {
+            double *v = &values[(size_t)a * readCount + r];
+            if (bestToZero) {
+                if (bestAbsoluteLikelihood == -INFINITY) *v = 0;
+                else if (worstLikelihoodCap != -INFINITY) *v = (*v < worstLikelihoodCap ? worstLikelihoodCap : *v) - bestAbsoluteLikelihood;
+                else *v -= bestAbsoluteLikelihood;
+            } else if (*v < worstLikelihoodCap) *v = worstLikelihoodCap;
+        }
+    }
+    return ORACLE_OK;
+}
+
+/* ReadLikelihoods.filterPoorlyModeledReads, :1059-1093, as flags: poorlyModelled[r] = 1 for the reads
+ * the Java removes.  ORACLE_ILLEGAL_STATE without alleles (:1060-1061), ORACLE_ILLEGAL_ARGUMENT for a
+ * rate that is not positive (:1062-1063). */
+int oracle_poorlyModelledReads(const double *values, int alleleCount, int readCount, const int32_t *readLengths,
+                               double maximumErrorPerBase, uint8_t *poorlyModelled) {
+    if (alleleCount == 0) return ORACLE_ILLEGAL_STATE;
+    if (isnan(maximumErrorPerBase) || maximumErrorPerBase <= 0.0) return ORACLE_ILLEGAL_ARGUMENT;
+    for (int r = 0; r < readCount; r++) {
+        const double maxErrorsForRead = fmin(2.0, ceil(readLengths[r] * maximumErrorPerBase));    /* :1082 */
+        const double log10MaxLikelihoodForTrueAllele = maxErrorsForRead * -4.0;                  /* :1083-1084 */
+        uint8_t poorly = 1;
+        for (int a = 0; a < alleleCount; a++)
+            if (values[(size_t)a * readCount + r] >= log10MaxLikelihoodForTrueAllele) { poorly = 0; break; }  /* :1088-1090 */
+        poorlyModelled[r] = poorly;
+    }
+    return ORACLE_OK;
+}
+
+/* ReadLikelihoods.marginalLikelihoods, :911-939, keeping every read: the new allele's likelihood is the
+ * maximum over the old alleles mapped to it (oldToNewAlleleIndexMap[a] = -1: dropped). */
+void oracle_marginalLikelihoods(const double *oldValues, int oldAlleleCount, int newAlleleCount, int readCount,
+                                const int32_t *oldToNewAlleleIndexMap, double *newValues) {
+    for (size_t k = 0; k < (size_t)newAlleleCount * readCount; k++) newValues[k] = -INFINITY;
+    for (int r = 0; r < readCount; r++)
+        for (int a = 0; a < oldAlleleCount; a++) {
+            const int n = oldToNewAlleleIndexMap[a];
+            if (n == -1) continue;
+            const double lk = oldValues[(size_t)a * readCount + r];
+            if (lk > newValues[(size_t)n * readCount + r]) newValues[(size_t)n * readCount + r] = lk;
+        }
+}
