@@ -24,6 +24,8 @@ class Batch:
     read_offsets: np.ndarray  # int32[num_reads + 1]
     hap_bases: np.ndarray     # uint8[total_hap_len]
     hap_offsets: np.ndarray   # int32[num_haps + 1]
+    read_mapq: np.ndarray = None  # uint8[num_reads] or None: cap on the read's base qualities
+    # ins_gop, del_gop and gcp may be None: the engine's defaults (Q45, Q45, 10)
 
     @property
     def num_reads(self):

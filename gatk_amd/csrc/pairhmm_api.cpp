@@ -179,6 +179,7 @@ struct gatk_pairhmm {
     float fp32_threshold = 1e-28f;
     int force_rows_per_lane = 0;
     int emit_mode = -1;  // -1: table when the haplotype alphabet allows it; 0: always compare bytes
+    bool squash_base_quals = false;  // base qualities under 18 count as 6 (PairHMM.java:54, QualityUtils.java:57)
     int stream_mode = -1;  // -1: haplotype runs in table modes; 0: one haplotype per work item
     int max_stream_haps = kMaxStreamHaps;
     bool force_fp64 = false;
@@ -250,7 +251,7 @@ int check_region(const gatk_pairhmm_batch& b, int k) {
     snprintf(where, sizeof where, " (region %d)", k);
     if (b.num_reads < 0 || b.num_haps < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("negative read or haplotype count") + where);
     if (b.num_reads == 0) return GATK_PAIRHMM_OK;  // PairHMM.java:193
-    if (!b.read_offsets || !b.read_bases || !b.read_quals || !b.ins_gop || !b.del_gop || !b.gcp)
+    if (!b.read_offsets || !b.read_bases || !b.read_quals)  // insertion / deletion / GCP arrays may be null: defaults
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("readBases cannot be null") + where);
     int read_max = 0, hap_max = 0;
     for (int r = 0; r < b.num_reads; ++r) {
@@ -310,6 +311,9 @@ void scan_alphabet(const uint8_t* p, int len, bool& has_n, bool& has_other) {
         else if (b != 'A' && b != 'C' && b != 'G' && b != 'T') has_other = true;
     }
 }
+
+constexpr int kDefaultIndelQual = 45;  // sam/GATKSAMRecord.java:61,298-322: reads without insertion / deletion qualities get a flat Q45
+constexpr int kDefaultGcp = 10;        // the constant gap-continuation penalty HaplotypeCaller passes (upstream; not in the reference tree)
 
 // A memcpy into the staging buffer.
 struct CopyJob {
@@ -587,8 +591,18 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     // ---- pass 2: lay the call out in the pinned staging buffer, one H2D copy ---------------------
     ArenaLayout L;
     const size_t rbytes = static_cast<size_t>(total_read_bytes);
-    const size_t o_rb = L.add(rbytes + 16), o_rq = L.add(rbytes + 16), o_ri = L.add(rbytes + 16), o_rd = L.add(rbytes + 16),
-                 o_rg = L.add(rbytes + 16);
+    // An optional per-base array that no region of the call supplies is not staged or copied at all: it
+    // goes behind everything that is uploaded and is filled with its default on the device.
+    bool have_ins = false, have_del = false, have_gcp = false, have_mapq = false;
+    for (int k = 0; k < num_regions; ++k) {
+        const gatk_pairhmm_batch& b = regions[k];
+        if (b.num_reads == 0 || b.num_haps == 0) continue;
+        have_ins |= b.ins_gop != nullptr; have_del |= b.del_gop != nullptr; have_gcp |= b.gcp != nullptr;
+        have_mapq |= b.read_mapq != nullptr;
+    }
+    const size_t o_rb = L.add(rbytes + 16), o_rq = L.add(rbytes + 16);
+    const size_t o_ri_up = have_ins ? L.add(rbytes + 16) : 0, o_rd_up = have_del ? L.add(rbytes + 16) : 0, o_rg_up = have_gcp ? L.add(rbytes + 16) : 0;
+    const size_t o_mapq = have_mapq ? L.add(static_cast<size_t>(total_reads) + 16) : 0;
     const size_t o_roff = L.add((total_reads + 1) * sizeof(int32_t));
     const size_t o_rout = L.add((total_reads + 1) * sizeof(int32_t));
     const size_t o_hpool = L.add(static_cast<size_t>(hap_pool_bytes) + 32);
@@ -601,9 +615,12 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     const size_t o_hsoff = L.add((total_haps + 1) * sizeof(int32_t));
     const size_t o_sdescs = L.add((stream_descs.size() + 1) * sizeof(StreamDesc));
     const size_t o_rinfo = L.add((total_reads + 1) * sizeof(ReadInfo));
+    const size_t upload_bytes = L.size;
+    const size_t o_ri = have_ins ? o_ri_up : L.add(rbytes + 16), o_rd = have_del ? o_rd_up : L.add(rbytes + 16),
+                 o_rg = have_gcp ? o_rg_up : L.add(rbytes + 16);
 
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(h->stage_in.ensure(L.size));
+    HIP_TRY(h->stage_in.ensure(upload_bytes));
     uint8_t* S = static_cast<uint8_t*>(h->stage_in.p);
     int32_t* roff = reinterpret_cast<int32_t*>(S + o_roff);
     int32_t* rout = reinterpret_cast<int32_t*>(S + o_rout);
@@ -624,9 +641,17 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         const size_t total = static_cast<size_t>(b.read_offsets[nr] - bo);
         copies.push_back({S + o_rb + rcur, b.read_bases + bo, total});
         copies.push_back({S + o_rq + rcur, b.read_quals + bo, total});
-        copies.push_back({S + o_ri + rcur, b.ins_gop + bo, total});
-        copies.push_back({S + o_rd + rcur, b.del_gop + bo, total});
-        copies.push_back({S + o_rg + rcur, b.gcp + bo, total});
+        // defaults for a region without the array, when other regions of the call have it
+        if (b.ins_gop) copies.push_back({S + o_ri + rcur, b.ins_gop + bo, total});
+        else if (have_ins) memset(S + o_ri + rcur, kDefaultIndelQual, total);
+        if (b.del_gop) copies.push_back({S + o_rd + rcur, b.del_gop + bo, total});
+        else if (have_del) memset(S + o_rd + rcur, kDefaultIndelQual, total);
+        if (b.gcp) copies.push_back({S + o_rg + rcur, b.gcp + bo, total});
+        else if (have_gcp) memset(S + o_rg + rcur, kDefaultGcp, total);
+        if (have_mapq) {
+            if (b.read_mapq) memcpy(S + o_mapq + ri, b.read_mapq, static_cast<size_t>(nr));
+            else memset(S + o_mapq + ri, 255, static_cast<size_t>(nr));
+        }
         for (int r = 0; r < nr; ++r) {
             rout[ri] = static_cast<int32_t>(R->region_out_off[k] + static_cast<int64_t>(r) * nh);
             roff[++ri] = static_cast<int32_t>(rcur + (b.read_offsets[r + 1] - bo));
@@ -669,7 +694,11 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         HIP_TRY(R->d_raw_out.ensure(std::max<size_t>(static_cast<size_t>(call_pairs) * sizeof(float), 16)));
         HIP_TRY(R->d_pair_lists.ensure(std::max<size_t>(static_cast<size_t>(stream_pairs) * sizeof(RerunPair), 16)));
     }
-    if (L.size) HIP_TRY(hipMemcpyAsync(R->d_arena.p, S, L.size, hipMemcpyHostToDevice, s));
+    if (upload_bytes) HIP_TRY(hipMemcpyAsync(R->d_arena.p, S, upload_bytes, hipMemcpyHostToDevice, s));
+    uint8_t* const Dw = R->d_arena.as<uint8_t>();
+    if (!have_ins) HIP_TRY(hipMemsetAsync(Dw + o_ri, kDefaultIndelQual, rbytes + 16, s));
+    if (!have_del) HIP_TRY(hipMemsetAsync(Dw + o_rd, kDefaultIndelQual, rbytes + 16, s));
+    if (!have_gcp) HIP_TRY(hipMemsetAsync(Dw + o_rg, kDefaultGcp, rbytes + 16, s));
     const uint8_t* D = R->d_arena.as<uint8_t>();
     DeviceBatch& B = R->base;
     B = DeviceBatch{};
@@ -683,6 +712,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     B.segs = reinterpret_cast<const SegDesc*>(D + o_segs);
     B.region_descs = reinterpret_cast<const RegionDesc*>(D + o_descs);
     B.total_read_bytes = total_read_bytes;
+    B.read_mapq = have_mapq ? D + o_mapq : nullptr;
     B.num_reads = static_cast<int32_t>(total_reads);
     B.num_haps = static_cast<int32_t>(total_haps);
     B.hap_stream_off = reinterpret_cast<const int32_t*>(D + o_hsoff);
@@ -726,6 +756,7 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     B.out = R->d_out.as<double>();
     B.error_word = R->d_counters.as<int32_t>();
     B.fp32_threshold = h->fp32_threshold;
+    B.squash_base_quals = h->squash_base_quals ? 1 : 0;
     HIP_TRY(launch_validate(B, s));
     B.pair_counts = R->d_counters.as<int32_t>() + 1 + kMaxBuckets;
     const bool streaming = R->any_stream && !h->force_fp64;
@@ -1179,6 +1210,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
     else if (n == "emit_mode") h->emit_mode = static_cast<int>(value);
     else if (n == "timing") h->timing = value != 0;
     else if (n == "stream_mode") h->stream_mode = static_cast<int>(value);
+    else if (n == "squash_base_quals") h->squash_base_quals = value != 0;
     else if (n == "pipeline_pairs") h->pipeline_pairs = std::max<int64_t>(0, static_cast<int64_t>(value));
     else if (n == "max_stream_haps") h->max_stream_haps = std::max(1, static_cast<int>(value));
     else return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "unknown option " + n);

@@ -105,6 +105,13 @@ constexpr int kMaxBuckets = 16;  // one bucket per rows-per-lane value in use
 constexpr int kStreamFrontPad = 64;  // entries in front of the haplotype stream: lanes ahead of the first column read here
 constexpr int kStreamBackPad = 128;  // entries behind it: draining lanes and the read-ahead land here
 
+// Base quality as the forward pass uses it: capped by the read's mapping quality when the caller
+// supplies one, and squashed to the minimum usable quality when under the threshold
+// (pairhmm/PairHMM.java:54 BASE_QUALITY_SCORE_THRESHOLD = 18, QualityUtils.java:57 MIN_USABLE_Q_SCORE = 6;
+// the method that applies them is upstream of the reference tree).
+constexpr unsigned kBaseQualityScoreThreshold = 18;
+constexpr unsigned kMinUsableQScore = 6;
+
 // Kernel arguments.  All pointers are device pointers.
 struct DeviceBatch {
     const uint8_t* read_bases;
@@ -112,6 +119,8 @@ struct DeviceBatch {
     const uint8_t* ins_gop;
     const uint8_t* del_gop;
     const uint8_t* gcp;
+    const uint8_t* read_mapq;      // [num_reads] cap on the read's base qualities, or null
+    int32_t squash_base_quals;     // 1: base qualities under 18 count as 6
     const int32_t* read_off;       // [num_reads + 1]
     const int32_t* read_out_base;  // [num_reads] index in out[] of (read, haplotype 0 of its region)
     const uint8_t* hap_pool;       // haplotype bytes, each haplotype starting on a 16-byte boundary

@@ -81,6 +81,14 @@ template <> struct Scale<double> { static constexpr int kExp2 = 1020; };
 
 constexpr unsigned kNoBase = 0x100;  // compares unequal to every haplotype byte
 
+// Base quality k of a read as the recurrence uses it (see kBaseQualityScoreThreshold).
+__device__ __forceinline__ unsigned effective_qual(const DeviceBatch& B, const int k, const int read) {
+    unsigned q = B.read_quals[k];
+    if (B.read_mapq) { const unsigned m = B.read_mapq[read]; q = q < m ? q : m; }
+    if (B.squash_base_quals && q < kBaseQualityScoreThreshold) q = kMinUsableQScore;
+    return q;
+}
+
 // Keeps a per-row constant in a register of its own type: without it the compiler carries the
 // double it was converted from through the loop and converts after every select.
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
@@ -303,7 +311,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
             } else if (ld.read_idx >= 0) {
                 if (i >= 1) {
                     const unsigned x = B.read_bases[ro + i - 1];
-                    const double e = B.err_prob[B.read_quals[ro + i - 1]];
+                    const double e = B.err_prob[effective_qual(B, ro + i - 1, ld.read_idx)];
                     xb = x;
                     p = 1.0 - e;                         // QualityUtils.qualToProb
                     q = (x == 'N') ? p : e / 3.0;        // a read 'N' matches every base
@@ -798,7 +806,7 @@ __device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_
         } else if (used) {
             if (i >= 1) {
                 const unsigned x = B.read_bases[ro + i - 1];
-                const double e = B.err_prob[B.read_quals[ro + i - 1]];
+                const double e = B.err_prob[effective_qual(B, ro + i - 1, pr.read_idx)];
                 xc = (x == 'A' ? 0u : x == 'C' ? 1u : x == 'T' ? 2u : x == 'G' ? 3u : 0x7fu) * kLutCodeStride;
                 p = 1.0 - e;
                 q = (x == 'N') ? p : e / 3.0;
@@ -1003,7 +1011,7 @@ __global__ void __launch_bounds__(256) expand_reads(const DeviceBatch B) {
         double t2 = 0.0, t4 = 1.0;  // a pad row hands its deletion mass down unweighted
         if (i >= 1 && i <= R) {
             const unsigned x = B.read_bases[ro + i - 1];
-            const double e = B.err_prob[B.read_quals[ro + i - 1]];
+            const double e = B.err_prob[effective_qual(B, ro + i - 1, read)];
             const unsigned ins = B.ins_gop[ro + i - 1] & 127u, del = B.del_gop[ro + i - 1] & 127u;
             const double t0 = B.match_to_match[ins * 128u + del];
             const double p = 1.0 - e;

@@ -51,7 +51,7 @@ class CBatch(C.Structure):
     _fields_ = [("num_reads", C.c_int32), ("num_haps", C.c_int32),
                 ("read_bases", C.c_void_p), ("read_quals", C.c_void_p), ("ins_gop", C.c_void_p),
                 ("del_gop", C.c_void_p), ("gcp", C.c_void_p), ("read_offsets", C.c_void_p),
-                ("hap_bases", C.c_void_p), ("hap_offsets", C.c_void_p)]
+                ("hap_bases", C.c_void_p), ("hap_offsets", C.c_void_p), ("read_mapq", C.c_void_p)]
 
 
 class CStats(C.Structure):
@@ -130,16 +130,19 @@ def _ptr(a):
 
 
 def to_cbatch(b: Batch, keep: list) -> CBatch:
-    arrs = [np.ascontiguousarray(x, dtype=np.uint8) for x in (b.read_bases, b.read_quals, b.ins_gop, b.del_gop, b.gcp)]
+    # ins_gop / del_gop / gcp set to None ask for the engine's defaults (Q45, Q45, 10)
+    arrs = [None if x is None else np.ascontiguousarray(x, dtype=np.uint8) for x in (b.read_bases, b.read_quals, b.ins_gop, b.del_gop, b.gcp)]
+    mapq = getattr(b, "read_mapq", None)
+    mapq = None if mapq is None else np.ascontiguousarray(mapq, dtype=np.uint8)
     ro = np.ascontiguousarray(b.read_offsets, dtype=np.int32)
     hb = np.ascontiguousarray(b.hap_bases, dtype=np.uint8)
     ho = np.ascontiguousarray(b.hap_offsets, dtype=np.int32)
     # a zero-size numpy array has a dangling data pointer: give the C side a real one
     dummy = np.zeros(1, dtype=np.uint8)
-    keep.extend(arrs + [ro, hb, ho, dummy])
-    p = [(_ptr(a) or dummy.ctypes.data) for a in arrs]
+    keep.extend(arrs + [ro, hb, ho, dummy, mapq])
+    p = [None if a is None else (_ptr(a) or dummy.ctypes.data) for a in arrs]
     return CBatch(b.num_reads, b.num_haps, p[0], p[1], p[2], p[3], p[4], ro.ctypes.data,
-                  _ptr(hb) or dummy.ctypes.data, ho.ctypes.data)
+                  _ptr(hb) or dummy.ctypes.data, ho.ctypes.data, None if mapq is None else (_ptr(mapq) or dummy.ctypes.data))
 
 
 class ReadLikelihoodsMatrix:

@@ -44,6 +44,15 @@ typedef struct gatk_pairhmm_resident gatk_pairhmm_resident; /* a set of region b
  * [read_offsets[r], read_offsets[r+1]).  Haplotype a occupies hap_bases[hap_offsets[a] ..
  * hap_offsets[a+1]).  Quality bytes are used unsigned; insertion/deletion/GCP values >= 128
  * are the Java "negative byte" error and base quality 255 is the out-of-bounds error.
+ *
+ * ins_gop and del_gop may be NULL: the read then has the flat Q45 GATKSAMRecord.getBaseInsertionQualities /
+ * getBaseDeletionQualities give a read without them (sam/GATKSAMRecord.java:61,298-322).  gcp may be NULL:
+ * 10 for every base, the constant HaplotypeCaller passes (upstream of the reference tree).  An array no
+ * region of a call supplies is neither staged nor copied.  read_mapq (one byte per read) may be NULL; when
+ * given, a read's base qualities are capped by it, and with the handle option "squash_base_quals" base
+ * qualities under BASE_QUALITY_SCORE_THRESHOLD = 18 (pairhmm/PairHMM.java:54) count as
+ * MIN_USABLE_Q_SCORE = 6 (QualityUtils.java:57) - the two steps the upstream likelihood engine applies to
+ * a read before the PairHMM sees it.
  */
 typedef struct gatk_pairhmm_batch {
     int32_t num_reads;
@@ -56,6 +65,7 @@ typedef struct gatk_pairhmm_batch {
     const int32_t* read_offsets; /* num_reads + 1 entries */
     const uint8_t* hap_bases;
     const int32_t* hap_offsets;  /* num_haps + 1 entries */
+    const uint8_t* read_mapq;    /* num_reads entries, or NULL */
 } gatk_pairhmm_batch;
 
 /* Counters of the last compute call on a handle. */
@@ -144,7 +154,8 @@ int gatk_pairhmm_device_count(int32_t* count);
  * "force_fp64" (1 = score everything in fp64), "emit_mode" (-1 = automatic, 0 = always compare bases
  * instead of using the per-wave emission table), "timing" (1 = fill the *_kernel_ms stats),
  * "stream_mode" (-1 = automatic: a wave scores a run of haplotypes back to back; 0 = one haplotype per
- * work item), "max_stream_haps" (longest run, 1..16), "pipeline_pairs" (default 131072: a compute_regions call with more
+ * work item), "max_stream_haps" (longest run, 1..16), "squash_base_quals" (1 = base qualities under 18 count as 6, see
+ * gatk_pairhmm_batch), "pipeline_pairs" (default 131072: a compute_regions call with more
  * pairs is cut between regions into parts of about that many pairs, and one part is planned and copied while
  * the kernels of the part before it run; 0 = never cut).  Planning options take effect at the next
  * upload or host-pointer call. */

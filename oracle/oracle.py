@@ -61,6 +61,10 @@ def lib():
         L.oracle_poorlyModelledReads.restype = C.c_int
         L.oracle_marginalLikelihoods.argtypes = [f64p, C.c_int, C.c_int, C.c_int, i32p, f64p]
         L.oracle_marginalLikelihoods.restype = None
+        L.oracle_modifyReadQualities.argtypes = [u8p, C.c_int, C.c_int, C.c_int]
+        L.oracle_modifyReadQualities.restype = None
+        L.oracle_defaultIndelQualities.argtypes = [u8p, C.c_int]
+        L.oracle_defaultIndelQualities.restype = None
         L.simd_pairhmm_batch.argtypes = [C.c_int, C.c_int, u8p, u8p, u8p, u8p, u8p, i32p, u8p, i32p, f64p, C.c_int, C.POINTER(C.c_int64)]
         L.simd_pairhmm_batch.restype = C.c_int
         L.simd_pairhmm_isa.restype = C.c_char_p
@@ -158,3 +162,16 @@ def marginal_likelihoods(values, old_to_new, new_allele_count):
     lib().oracle_marginalLikelihoods(v.ctypes.data_as(C.POINTER(C.c_double)), a, new_allele_count, r, m.ctypes.data_as(C.POINTER(C.c_int32)),
                                      out.ctypes.data_as(C.POINTER(C.c_double)))
     return out
+
+
+def modify_read_qualities(quals, mapq=None, squash=False):
+    """Base qualities of one read as the PairHMM receives them: capped by mapq (None: no cap), squashed under 18."""
+    q = np.array(quals, dtype=np.uint8)
+    lib().oracle_modifyReadQualities(q.ctypes.data_as(C.POINTER(C.c_uint8)), len(q), -1 if mapq is None else int(mapq), 1 if squash else 0)
+    return q
+
+
+def default_indel_qualities(n):
+    q = np.zeros(n, dtype=np.uint8)
+    lib().oracle_defaultIndelQualities(q.ctypes.data_as(C.POINTER(C.c_uint8)), n)
+    return q

@@ -568,3 +568,26 @@ void oracle_marginalLikelihoods(const double *oldValues, int oldAlleleCount, int
             if (lk > newValues[(size_t)n * readCount + r]) newValues[(size_t)n * readCount + r] = lk;
         }
 }
+
+/* ----------------------------------------------------------------------------------
+ * Upstream of the path: what a read's qualities look like when the PairHMM receives them.
+ * In the reference tree: the flat Q45 default of reads without insertion / deletion qualities
+ * (sam/GATKSAMRecord.java:61,298-322) and the two constants of the base-quality squashing
+ * (pairhmm/PairHMM.java:54 BASE_QUALITY_SCORE_THRESHOLD = 18, QualityUtils.java:57
+ * MIN_USABLE_Q_SCORE = 6).  The method that applies the constants (cap by mapping quality, then
+ * squash) belongs to the likelihood engine upstream of the tree; it is restated from its
+ * documented behaviour, not from code.
+ * ---------------------------------------------------------------------------------- */
+void oracle_defaultIndelQualities(uint8_t *quals, int n) {
+    for (int i = 0; i < n; i++) quals[i] = 45;
+}
+
+/* mapq < 0: no cap. */
+void oracle_modifyReadQualities(uint8_t *quals, int n, int mapq, int squash) {
+    for (int i = 0; i < n; i++) {
+        int q = quals[i];
+        if (mapq >= 0 && q > mapq) q = mapq;
+        if (squash && q < 18) q = 6;
+        quals[i] = (uint8_t)q;
+    }
+}

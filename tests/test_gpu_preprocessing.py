@@ -1,0 +1,65 @@
+"""Read pre-processing at the boundary: default insertion / deletion / GCP arrays, the mapping-quality
+cap and the base-quality squashing, against the oracle's restatement applied on the host."""
+import numpy as np
+import pytest
+
+from gatk_amd import synth
+from gatk_amd.batch import Batch
+
+pytestmark = pytest.mark.gpu
+
+
+def replace(b, **kw):
+    f = dict(read_bases=b.read_bases, read_quals=b.read_quals, ins_gop=b.ins_gop, del_gop=b.del_gop, gcp=b.gcp,
+             read_offsets=b.read_offsets, hap_bases=b.hap_bases, hap_offsets=b.hap_offsets, read_mapq=b.read_mapq)
+    f.update(kw)
+    return Batch(**f)
+
+
+def test_missing_arrays_mean_the_reference_defaults(hmm, oracle):
+    b = synth.make_batch(40, 7, 101, 300, seed=8)  # explicit Q45 / Q45 / 10 arrays
+    n = len(b.read_bases)
+    assert (b.ins_gop == oracle.default_indel_qualities(n)).all() and (b.del_gop == 45).all() and (b.gcp == 10).all()
+    want = hmm.compute_batch(b)
+    for missing in ({"ins_gop": None}, {"del_gop": None, "gcp": None}, {"ins_gop": None, "del_gop": None, "gcp": None}):
+        np.testing.assert_array_equal(hmm.compute_batch(replace(b, **missing)), want)
+
+
+def test_regions_with_and_without_arrays_in_one_call(hmm, oracle):
+    regions = synth.make_regions(6, seed=12, coverage=6, read_len=80)
+    explicit = hmm.compute_regions(regions)
+    mixed = [replace(b, ins_gop=None, del_gop=None, gcp=None) if k % 2 else b for k, b in enumerate(regions)]
+    for a, c in zip(explicit, hmm.compute_regions(mixed)):
+        np.testing.assert_array_equal(a, c)
+    # a region with its own gap-open qualities next to regions without any
+    varied = synth.make_batch(20, 5, 90, 260, seed=13, gop_model="random")
+    outs = hmm.compute_regions([replace(regions[0], ins_gop=None, del_gop=None, gcp=None), varied])
+    np.testing.assert_array_equal(outs[0], explicit[0])
+    rc, want = oracle.compute_likelihoods(varied, oracle.LOGLESS, fast_threads=4)
+    assert rc == 0 and np.abs(outs[1] - want).max() <= 1e-3
+
+
+@pytest.mark.parametrize("squash", [False, True])
+def test_mapq_cap_and_squashing(hmm, oracle, squash):
+    b = synth.make_batch(60, 6, 101, 300, seed=14, mean_qual=22.0)
+    rng = np.random.default_rng(5)
+    mapq = rng.choice([0, 10, 20, 37, 60, 255], size=b.num_reads).astype(np.uint8)
+    quals = b.read_quals.copy()
+    for r in range(b.num_reads):
+        lo, hi = b.read_offsets[r], b.read_offsets[r + 1]
+        quals[lo:hi] = oracle.modify_read_qualities(quals[lo:hi], mapq[r], squash)
+    assert (quals != b.read_quals).any()
+    pre = replace(b, read_quals=quals)
+    rc, want = oracle.compute_likelihoods(pre, oracle.LOGLESS, fast_threads=4)
+    assert rc == 0
+    hmm.set_option("squash_base_quals", 1 if squash else 0)
+    try:
+        got = hmm.compute_batch(replace(b, read_mapq=mapq))
+        hmm.set_option("fp32_threshold", 3e38)  # and through the fp64 pass
+        got64 = hmm.compute_batch(replace(b, read_mapq=mapq))
+    finally:
+        hmm.set_option("squash_base_quals", 0)
+        hmm.set_option("fp32_threshold", 1e-28)
+    np.testing.assert_array_equal(got, hmm.compute_batch(pre))  # same arithmetic on the same effective qualities
+    assert np.abs(got - want).max() <= 1e-3
+    assert np.abs(got64 - want).max() <= 1e-9
