@@ -246,6 +246,33 @@ int choose_rows_per_lane(const std::vector<int>& lens_desc, int64_t num_haps, do
     return best_k;
 }
 
+// Rows per lane for a wave-group whose longest read has `longest` bases, in a call large enough to keep the
+// device full: the value with the fewest modelled vector instructions per read, taking the group's other
+// reads to be as long as its longest (reads are packed longest first, so they are close) and a typical
+// haplotype length for the weight of the pipeline fill.  A table: the planner asks once per wave-group.
+int choose_group_rows_per_lane(int longest) {
+    static const std::array<uint8_t, kWave * kMaxRowsPerLane> table = [] {
+        std::array<uint8_t, kWave * kMaxRowsPerLane> t{};
+        for (int len = 1; len <= kWave * kMaxRowsPerLane - 2; ++len) {
+            const int min_k = (len + 1 + kWave) / kWave;
+            int best_k = kMaxRowsPerLane;
+            double best = std::numeric_limits<double>::infinity();
+            for (int k : kRowsPerLaneChoices) {
+                if (k < min_k) continue;
+                if (k > 12 && best_k != kMaxRowsPerLane) break;  // more rows cost a wave per SIMD: only for long reads
+                const int lanes = (len + 1 + k) / k;
+                double cost = (5.0 * k + 6.0) * (400.0 + lanes) / (kWave / lanes);
+                if (k > 10) cost *= 1.03;  // the one-haplotype fp64 pass spills beyond 10 rows
+                if (k > 12) cost *= 1.15;  // two waves per SIMD instead of three
+                if (cost < best * 0.995) { best = cost; best_k = k; }
+            }
+            t[len] = static_cast<uint8_t>(best_k);
+        }
+        return t;
+    }();
+    return table[longest];
+}
+
 int check_region(const gatk_pairhmm_batch& b, int k) {
     char where[64];
     snprintf(where, sizeof where, " (region %d)", k);
@@ -432,17 +459,27 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         });
         lens_desc.clear();
         for (int r : order) lens_desc.push_back(b.read_offsets[r + 1] - b.read_offsets[r]);
-        const int K = choose_rows_per_lane(lens_desc, nh, static_cast<double>(hap_total) / nh, call_pairs, h->force_rows_per_lane);
-        rp.K = K;
-        rp.group_begin = static_cast<int>(groups.size());
+        // Rows per lane: one value for the region when the call is too small to fill the device (the model
+        // then trades instruction count against waves in flight); otherwise every wave-group takes the
+        // value that suits its own reads, so a region whose reads differ in length spreads over buckets.
+        const double mean_hap = static_cast<double>(hap_total) / nh;
+        const bool per_group = h->force_rows_per_lane == 0 && call_pairs >= 4 * static_cast<int64_t>(h->wave_slots);
+        const int region_k = per_group ? 0 : choose_rows_per_lane(lens_desc, nh, mean_hap, call_pairs, h->force_rows_per_lane);
         size_t pos = 0;
-        int max_fill = 0;
         while (pos < order.size()) {
+            const int K = per_group ? choose_group_rows_per_lane(lens_desc[pos]) : region_k;
+            if (plans.empty() || plans.back().region != k || plans.back().K != K) {
+                rp.K = K;
+                rp.group_begin = static_cast<int>(groups.size());
+                rp.num_groups = 0;
+                rp.cost = 0;
+                plans.push_back(rp);
+            }
             GroupDesc g{static_cast<int32_t>(segs.size()), 0, 0};
             int used = 0, max_seg = 0;
             while (pos < order.size()) {
                 const int r = order[pos];
-                const int len = b.read_offsets[r + 1] - b.read_offsets[r];
+                const int len = lens_desc[pos];
                 const int seg = (len + 1 + K) / K;  // rows >= len + 2: a pad row in front, the sum row behind
                 if (used + seg > kWave) break;
                 segs.push_back(SegDesc{rp.read_begin + r, static_cast<uint8_t>(used), static_cast<uint8_t>(seg), static_cast<uint16_t>(len)});
@@ -451,15 +488,13 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
                 ++g.num_segs; ++pos;
             }
             g.fill = static_cast<int16_t>(max_seg - 1);
-            max_fill = std::max(max_fill, max_seg - 1);
             groups.push_back(g);
             R->group_segs.push_back(static_cast<uint8_t>(g.num_segs));
+            ++plans.back().num_groups;
+            plans.back().cost = std::max(plans.back().cost, rp.hap_max + max_seg - 1);
         }
-        rp.num_groups = static_cast<int>(groups.size()) - rp.group_begin;
-        rp.cost = rp.hap_max + max_fill;
         read_cursor += nr;
         hap_cursor += nh;
-        if (rp.num_groups > 0) plans.push_back(rp);
     }
 
     // PairHMM.java:200-201: grow the instance's maxima when a batch exceeds them
@@ -543,13 +578,12 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             int read_max = 1;
             for (size_t j = bucket_first; j < i; ++j) {
                 const RegionPlan& rp = plans[by_cost[j]];
-                const gatk_pairhmm_batch& b = regions[rp.region];
-                read_max = std::max(read_max, rp.read_max);
-                for (int r = 0; r < rp.nr; ++r) {
-                    if (b.read_offsets[r + 1] == b.read_offsets[r]) continue;  // zero-length reads have no work item
-                    read_info[rp.read_begin + r].bucket = bucket_index;
-                    bk.num_pairs += rp.nh;
-                }
+                for (int g = rp.group_begin; g < rp.group_begin + rp.num_groups; ++g)
+                    for (int x = groups[g].seg_begin; x < groups[g].seg_begin + groups[g].num_segs; ++x) {
+                        read_info[segs[x].read_idx].bucket = bucket_index;  // zero-length reads are in no segment
+                        read_max = std::max<int>(read_max, segs[x].read_len);
+                        bk.num_pairs += rp.nh;
+                    }
             }
             // The pair pass picks its own rows per lane: at most 8 (more spills in double), the value that
             // wastes the fewest lane-rows for the bucket's longest read, the smaller one on a tie (the
