@@ -1,0 +1,380 @@
+// Smith-Waterman pairwise alignment for gfx950 (wave64): kernels and the C-ABI of
+// include/gatk_smithwaterman.h.
+//
+// The algorithm is the reference's (smithwaterman/SWPairwiseAlignment.java): an integer affine-gap matrix
+// in which a cell takes the best of the diagonal step, the best horizontal gap ending in it and the best
+// vertical gap ending in it, the two gaps tracked by running "best gap so far" values and their lengths
+// (calculateMatrix, :223-332); then a back-track from an end cell chosen per overhang strategy
+// (calculateCigar, :350-470).
+//
+// Mapping: one wave per pair.  Lane t owns reference rows t*K+1 .. t*K+K; at step s it is at alternate
+// column s - t + 1, so the three values that flow down a column (the cell above, the best vertical gap
+// and its length) cross lanes once per step with v_mov_b32_dpp wave_shr:1, and everything that flows
+// along a row (the cell to the left, the best horizontal gap and its length) stays in the lane's
+// registers.  The alternate sequence sits in LDS.  The back-track matrix goes to global memory as int16
+// (a gap is never longer than a sequence); a second kernel, one thread per pair, picks the end cell and
+// walks it.  The host reverses and consolidates the few CIGAR elements.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gatk_smithwaterman.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kMaxRowsPerLane = 32;
+constexpr int kMaxRef = kWave * kMaxRowsPerLane;  // 2048
+constexpr int kMaxAlt = 16000;
+constexpr int kLowInit = INT_MIN / 2;             // lowInitValue, :235
+constexpr int kMatrixMinCutoff = -100000000;      // (int) -1e8, :233 (the static cutoff flag is false)
+
+struct PairDesc {
+    int64_t ref_off, alt_off;      // byte offsets into the sequence pool
+    int64_t btrack_off;            // int16 offset of this pair's (n+1) x (m+1) back-track matrix
+    int64_t edge_off;              // int32 offset of its last-column (n+1) and bottom-row (m+1) scores
+    int64_t elem_off;              // int32 offset of its raw CIGAR element list (2 ints per element)
+    int32_t n, m;                  // reference / alternate length
+    int32_t elem_cap;
+    int32_t reserved;
+};
+
+struct PairResult {
+    int32_t num_elems;   // raw elements written, last CIGAR element first
+    int32_t offset;      // alignment offset
+};
+
+struct SwArgs {
+    const uint8_t* pool;
+    const PairDesc* pairs;
+    int16_t* btrack;
+    int32_t* edges;
+    int32_t* elems;
+    PairResult* results;
+    int32_t num_pairs;
+    int32_t w_match, w_mismatch, w_open, w_extend;
+    int32_t strategy;
+};
+
+__device__ __forceinline__ int shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
+
+// First-row / first-column scores: gap penalties when overhangs count as indels (:244-261), else 0.
+__device__ __forceinline__ int edge_score(const SwArgs& A, int k) {
+    if (k <= 0 || (A.strategy != GATK_SW_INDEL && A.strategy != GATK_SW_LEADING_INDEL)) return 0;
+    return A.w_open + (k - 1) * A.w_extend;
+}
+
+template <int K>
+__global__ void __launch_bounds__(kWave) sw_fill(const SwArgs A, const int first_pair) {
+    extern __shared__ uint8_t alt_lds[];  // [64 pad][alternate][64 pad]
+    const int pair_idx = first_pair + blockIdx.x;
+    if (pair_idx >= A.num_pairs) return;
+    const PairDesc P = A.pairs[pair_idx];
+    const int lane = threadIdx.x;
+    const int n = P.n, m = P.m, ncol = m + 1;
+    const uint8_t* ref = A.pool + P.ref_off;
+    const uint8_t* alt = A.pool + P.alt_off;
+    for (int x = lane; x < m + 2 * kWave; x += kWave) {
+        const int j = x - kWave;
+        alt_lds[x] = (j >= 0 && j < m) ? alt[j] : 0;
+    }
+    __syncthreads();
+
+    const int row0 = lane * K + 1;  // this lane's first row (1-based)
+    int a_base[K], left[K], bgh[K], gsh[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        const int i = row0 + r;
+        a_base[r] = i <= n ? ref[i - 1] : 0x100;  // rows past the end match nothing
+        left[r] = edge_score(A, i);               // sw[i][0]
+        bgh[r] = kLowInit;
+        gsh[r] = 0;
+    }
+    int diag0 = edge_score(A, row0 - 1);  // sw[row0 - 1][0]
+    int out_sw = 0, out_bgv = kLowInit, out_gsv = 0;  // what this lane hands down: its last row at its current column
+    int16_t* const bt = A.btrack + P.btrack_off;
+    int32_t* const last_col = A.edges + P.edge_off;
+    int32_t* const bottom = last_col + (n + 1);
+    const int steps = m + (n + K - 1) / K - 1;
+    for (int s = 0; s < steps; ++s) {
+        int up = shr1(out_sw), bgv = shr1(out_bgv), gsv = shr1(out_gsv);
+        const int j = s - lane + 1;  // 1-based column
+        if (lane == 0) { up = edge_score(A, j); bgv = kLowInit; gsv = 0; }  // row 0: sw[0][j], no vertical gap yet
+        if (j >= 1 && j <= m) {
+            const int b_base = alt_lds[kWave + j - 1];
+            const int up_in = up;
+            int diag = diag0;
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                const int i = row0 + r;
+                const int old_left = left[r];
+                const int step_diag = diag + (a_base[r] == b_base ? A.w_match : A.w_mismatch);
+                // best vertical gap ending here, :283-298
+                int prev_gap = up + A.w_open;
+                bgv += A.w_extend;
+                if (prev_gap > bgv) { bgv = prev_gap; gsv = 1; } else ++gsv;
+                // best horizontal gap ending here, :305-318
+                prev_gap = old_left + A.w_open;
+                bgh[r] += A.w_extend;
+                if (prev_gap > bgh[r]) { bgh[r] = prev_gap; gsh[r] = 1; } else ++gsh[r];
+                // priority: diagonal, then right, then down, :320-331
+                int val, btr;
+                if (step_diag >= bgv && step_diag >= bgh[r]) { val = step_diag; btr = 0; }
+                else if (bgh[r] >= bgv) { val = bgh[r]; btr = -gsh[r]; }
+                else { val = bgv; btr = gsv; }
+                val = val > kMatrixMinCutoff ? val : kMatrixMinCutoff;
+                if (i <= n) {
+                    bt[static_cast<int64_t>(i) * ncol + j] = static_cast<int16_t>(btr);
+                    if (j == m) last_col[i] = val;
+                    if (i == n) bottom[j] = val;
+                }
+                left[r] = val;
+                diag = old_left;  // sw[i][j-1] is the diagonal of row i + 1
+                up = val;
+            }
+            diag0 = up_in;
+            out_sw = up; out_bgv = bgv; out_gsv = gsv;
+        }
+    }
+}
+
+// calculateCigar, :350-470, one thread per pair: the raw element list (last element first) and the offset.
+__global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.num_pairs) return;
+    const PairDesc P = A.pairs[k];
+    const int refLength = P.n, altLength = P.m, ncol = P.m + 1;
+    const int16_t* bt = A.btrack + P.btrack_off;
+    const int32_t* last_col = A.edges + P.edge_off;
+    const int32_t* bottom = last_col + (refLength + 1);
+    int32_t* elems = A.elems + P.elem_off;
+    int count = 0;
+    auto add = [&](int op, int len) {
+        if (count < P.elem_cap) { elems[2 * count] = op; elems[2 * count + 1] = len; }
+        ++count;
+    };
+    int p1 = 0, p2 = 0, maxscore = INT_MIN, segment_length = 0;
+    if (A.strategy == GATK_SW_INDEL) {
+        p1 = refLength; p2 = altLength;
+    } else {
+        p2 = altLength;
+        for (int i = 1; i <= refLength; ++i) {
+            const int cur = last_col[i];
+            if (cur >= maxscore) { p1 = i; maxscore = cur; }
+        }
+        if (A.strategy != GATK_SW_LEADING_INDEL) {
+            for (int j = 1; j <= altLength; ++j) {
+                const int cur = bottom[j];
+                if (cur > maxscore || (cur == maxscore && abs(refLength - j) < abs(p1 - p2))) {
+                    p1 = refLength; p2 = j; maxscore = cur;
+                    segment_length = altLength - j;
+                }
+            }
+        }
+    }
+    if (segment_length > 0 && A.strategy == GATK_SW_SOFTCLIP) { add(GATK_SW_OP_S, segment_length); segment_length = 0; }
+    int state = GATK_SW_OP_M;
+    do {
+        const int btr = bt[static_cast<int64_t>(p1) * ncol + p2];
+        int new_state, step_length = 1;
+        if (btr > 0) { new_state = GATK_SW_OP_D; step_length = btr; }
+        else if (btr < 0) { new_state = GATK_SW_OP_I; step_length = -btr; }
+        else new_state = GATK_SW_OP_M;
+        if (new_state == GATK_SW_OP_M) { --p1; --p2; }
+        else if (new_state == GATK_SW_OP_I) p2 -= step_length;
+        else p1 -= step_length;
+        if (new_state == state) segment_length += step_length;
+        else { add(state, segment_length); segment_length = step_length; state = new_state; }
+    } while (p1 > 0 && p2 > 0);
+    int offset;
+    if (A.strategy == GATK_SW_SOFTCLIP) {
+        add(state, segment_length);
+        if (p2 > 0) add(GATK_SW_OP_S, p2);
+        offset = p1;
+    } else if (A.strategy == GATK_SW_IGNORE) {
+        add(state, segment_length + p2);
+        offset = p1 - p2;
+    } else {
+        add(state, segment_length);
+        if (p1 > 0) add(GATK_SW_OP_D, p1);
+        else if (p2 > 0) add(GATK_SW_OP_I, p2);
+        offset = 0;
+    }
+    A.results[k] = PairResult{count, offset};
+}
+
+thread_local std::string g_sw_error;
+
+int fail(int code, const std::string& msg) {
+    g_sw_error = msg;
+    return code;
+}
+
+#define SW_TRY(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail(GATK_SW_DEVICE_ERROR, std::string(#expr ": ") + hipGetErrorString(e_)); \
+    } while (0)
+
+// Grow-only device scratch of the calling thread (one per device it has used).
+struct Scratch {
+    int device = -1;
+    void* p = nullptr;
+    size_t cap = 0;
+};
+thread_local std::vector<Scratch> g_scratch;
+
+hipError_t scratch_for(int device, size_t bytes, void** out) {
+    Scratch* s = nullptr;
+    for (auto& x : g_scratch)
+        if (x.device == device) s = &x;
+    if (!s) { g_scratch.push_back(Scratch{device, nullptr, 0}); s = &g_scratch.back(); }
+    if (bytes > s->cap) {
+        if (s->p) { hipError_t e = hipFree(s->p); s->p = nullptr; s->cap = 0; if (e != hipSuccess) return e; }
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipMalloc(&s->p, want);
+        if (e != hipSuccess) return e;
+        s->cap = want;
+    }
+    *out = s->p;
+    return hipSuccess;
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+template <int K>
+hipError_t launch_fill(const SwArgs& A, int num_pairs, size_t lds, hipStream_t stream) {
+    hipLaunchKernelGGL((sw_fill<K>), dim3(num_pairs), dim3(kWave), lds, stream, A, 0);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gatk_sw_last_error(void) { return g_sw_error.c_str(); }
+
+int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* references, const int32_t* reference_lengths,
+                  const uint8_t* const* alternates, const int32_t* alternate_lengths, const gatk_sw_parameters* parameters,
+                  int32_t overhang_strategy, int32_t cigar_capacity, int32_t* cigar_ops, int32_t* cigar_lengths,
+                  int32_t* cigar_counts, int32_t* alignment_offsets) {
+    if (num_pairs < 0) return fail(GATK_SW_ILLEGAL_ARGUMENT, "negative pair count");
+    if (num_pairs == 0) return GATK_SW_OK;
+    if (!references || !reference_lengths || !alternates || !alternate_lengths || !parameters || !cigar_ops || !cigar_lengths ||
+        !cigar_counts || !alignment_offsets)
+        return fail(GATK_SW_ILLEGAL_ARGUMENT, "argument cannot be null");
+    if (overhang_strategy < GATK_SW_SOFTCLIP || overhang_strategy > GATK_SW_IGNORE) return fail(GATK_SW_ILLEGAL_ARGUMENT, "unknown overhang strategy");
+    if (cigar_capacity <= 0) return fail(GATK_SW_ILLEGAL_ARGUMENT, "cigar_capacity must be positive");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(GATK_SW_DEVICE_ERROR, "no HIP device is visible: the Smith-Waterman engine has no CPU fallback");
+    if (device < 0 || device >= n_dev) return fail(GATK_SW_DEVICE_ERROR, "device index out of range");
+
+    // ---- layout -----------------------------------------------------------------------------------
+    std::vector<PairDesc> pairs(num_pairs);
+    size_t pool_bytes = 0, bt_entries = 0, edge_ints = 0, elem_ints = 0;
+    int max_n = 0, max_m = 0;
+    for (int k = 0; k < num_pairs; ++k) {
+        const int n = reference_lengths[k], m = alternate_lengths[k];
+        if (!references[k] || n <= 0 || !alternates[k] || m <= 0)  // SWPairwiseAlignment.java:183-184
+            return fail(GATK_SW_ILLEGAL_ARGUMENT, "Non-null, non-empty sequences are required for the Smith-Waterman calculation (pair " + std::to_string(k) + ")");
+        if (n > kMaxRef || m > kMaxAlt)
+            return fail(GATK_SW_ILLEGAL_ARGUMENT, "sequence too long: reference up to " + std::to_string(kMaxRef) + ", alternate up to " +
+                                                      std::to_string(kMaxAlt) + " bases (pair " + std::to_string(k) + ")");
+        PairDesc& P = pairs[k];
+        P.n = n; P.m = m;
+        P.ref_off = static_cast<int64_t>(pool_bytes); pool_bytes += align_up(n, 16);
+        P.alt_off = static_cast<int64_t>(pool_bytes); pool_bytes += align_up(m, 16);
+        P.btrack_off = static_cast<int64_t>(bt_entries); bt_entries += align_up(static_cast<size_t>(n + 1) * (m + 1), 8);
+        P.edge_off = static_cast<int64_t>(edge_ints); edge_ints += static_cast<size_t>(n + 1) + (m + 1);
+        // an element is added when the back-track changes state, plus a few at the ends: a list that outgrows
+        // this cannot consolidate into cigar_capacity elements
+        P.elem_cap = std::min(n + m + 8, 2 * cigar_capacity + 16);
+        P.elem_off = static_cast<int64_t>(elem_ints); elem_ints += 2 * static_cast<size_t>(P.elem_cap);
+        max_n = std::max(max_n, n); max_m = std::max(max_m, m);
+    }
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t at = off; off = align_up(off + bytes, 256); return at; };
+    const size_t o_pool = carve(pool_bytes), o_pairs = carve(pairs.size() * sizeof(PairDesc));
+    const size_t upload_bytes = off;
+    const size_t o_bt = carve(bt_entries * sizeof(int16_t)), o_edges = carve(edge_ints * sizeof(int32_t)),
+                 o_elems = carve(elem_ints * sizeof(int32_t)), o_results = carve(pairs.size() * sizeof(PairResult));
+    std::vector<uint8_t> host(upload_bytes, 0);
+    for (int k = 0; k < num_pairs; ++k) {
+        memcpy(host.data() + o_pool + pairs[k].ref_off, references[k], pairs[k].n);
+        memcpy(host.data() + o_pool + pairs[k].alt_off, alternates[k], pairs[k].m);
+    }
+    memcpy(host.data() + o_pairs, pairs.data(), pairs.size() * sizeof(PairDesc));
+
+    // ---- device -----------------------------------------------------------------------------------
+    SW_TRY(hipSetDevice(device));
+    void* base = nullptr;
+    SW_TRY(scratch_for(device, off, &base));
+    uint8_t* D = static_cast<uint8_t*>(base);
+    hipStream_t stream = nullptr;  // the null stream: calls of one thread are ordered, results are fetched synchronously
+    SW_TRY(hipMemcpyAsync(D, host.data(), upload_bytes, hipMemcpyHostToDevice, stream));
+    SwArgs A{};
+    A.pool = D + o_pool;
+    A.pairs = reinterpret_cast<const PairDesc*>(D + o_pairs);
+    A.btrack = reinterpret_cast<int16_t*>(D + o_bt);
+    A.edges = reinterpret_cast<int32_t*>(D + o_edges);
+    A.elems = reinterpret_cast<int32_t*>(D + o_elems);
+    A.results = reinterpret_cast<PairResult*>(D + o_results);
+    A.num_pairs = num_pairs;
+    A.w_match = parameters->w_match; A.w_mismatch = parameters->w_mismatch; A.w_open = parameters->w_open; A.w_extend = parameters->w_extend;
+    A.strategy = overhang_strategy;
+    // rows per lane: the smallest instantiation that holds the longest reference of the call
+    const size_t lds = static_cast<size_t>(max_m) + 2 * kWave;
+    const int need = (max_n + kWave - 1) / kWave;
+    hipError_t e;
+    if (need <= 1) e = launch_fill<1>(A, num_pairs, lds, stream);
+    else if (need <= 2) e = launch_fill<2>(A, num_pairs, lds, stream);
+    else if (need <= 4) e = launch_fill<4>(A, num_pairs, lds, stream);
+    else if (need <= 8) e = launch_fill<8>(A, num_pairs, lds, stream);
+    else if (need <= 16) e = launch_fill<16>(A, num_pairs, lds, stream);
+    else e = launch_fill<32>(A, num_pairs, lds, stream);
+    SW_TRY(e);
+    hipLaunchKernelGGL(sw_backtrack, dim3((num_pairs + 63) / 64), dim3(64), 0, stream, A);
+    SW_TRY(hipGetLastError());
+    std::vector<PairResult> results(num_pairs);
+    std::vector<int32_t> elems(elem_ints);
+    SW_TRY(hipMemcpyAsync(results.data(), D + o_results, results.size() * sizeof(PairResult), hipMemcpyDeviceToHost, stream));
+    SW_TRY(hipMemcpyAsync(elems.data(), D + o_elems, elems.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    SW_TRY(hipStreamSynchronize(stream));
+
+    // ---- Collections.reverse + AlignmentUtils.consolidateCigar (sam/AlignmentUtils.java:698-727) -------
+    int rc = GATK_SW_OK;
+    for (int k = 0; k < num_pairs; ++k) {
+        const int32_t* raw = elems.data() + pairs[k].elem_off;
+        if (results[k].num_elems > pairs[k].elem_cap)
+            rc = fail(GATK_SW_CIGAR_TOO_LONG, "pair " + std::to_string(k) + " needs more than cigar_capacity elements");
+        const int count = std::min(results[k].num_elems, pairs[k].elem_cap);
+        int32_t* ops = cigar_ops + static_cast<size_t>(k) * cigar_capacity;
+        int32_t* lens = cigar_lengths + static_cast<size_t>(k) * cigar_capacity;
+        int out = 0, sum = 0, last = -1;
+        auto emit = [&](int op, int len) {
+            if (out < cigar_capacity) { ops[out] = op; lens[out] = len; }
+            else rc = fail(GATK_SW_CIGAR_TOO_LONG, "pair " + std::to_string(k) + " needs more than cigar_capacity elements");
+            ++out;
+        };
+        for (int x = count - 1; x >= 0; --x) {
+            const int op = raw[2 * x], len = raw[2 * x + 1];
+            if (len == 0) continue;
+            if (last != -1 && last != op) { emit(last, sum); sum = 0; }
+            sum += len;
+            last = op;
+        }
+        if (sum > 0) emit(last, sum);
+        cigar_counts[k] = out;
+        alignment_offsets[k] = results[k].offset;
+    }
+    return rc;
+}
+
+}  // extern "C"

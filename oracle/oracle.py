@@ -65,6 +65,9 @@ def lib():
         L.oracle_modifyReadQualities.restype = None
         L.oracle_defaultIndelQualities.argtypes = [u8p, C.c_int]
         L.oracle_defaultIndelQualities.restype = None
+        L.oracle_sw_align.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      i32p, i32p, C.c_int, i32p, i32p, i32p, i32p]
+        L.oracle_sw_align.restype = C.c_int
         L.simd_pairhmm_batch.argtypes = [C.c_int, C.c_int, u8p, u8p, u8p, u8p, u8p, i32p, u8p, i32p, f64p, C.c_int, C.POINTER(C.c_int64)]
         L.simd_pairhmm_batch.restype = C.c_int
         L.simd_pairhmm_isa.restype = C.c_char_p
@@ -175,3 +178,26 @@ def default_indel_qualities(n):
     q = np.zeros(n, dtype=np.uint8)
     lib().oracle_defaultIndelQualities(q.ctypes.data_as(C.POINTER(C.c_uint8)), n)
     return q
+
+
+# ---- Smith-Waterman (smithwaterman/SWPairwiseAlignment.java) ----
+SW_SOFTCLIP, SW_INDEL, SW_LEADING_INDEL, SW_IGNORE = 0, 1, 2, 3
+SW_ORIGINAL_DEFAULT = (3, -1, -4, -3)      # SWParameterSet.java:38
+SW_STANDARD_NGS = (25, -50, -110, -6)      # SWParameterSet.java:43
+
+
+def sw_align(reference, alternate, parameters=SW_ORIGINAL_DEFAULT, strategy=SW_SOFTCLIP, matrices=False):
+    """SWPairwiseAlignment(reference, alternate, parameters, strategy): returns (rc, cigar string, alignment offset)
+    and, with matrices=True, also the sw and btrack matrices."""
+    ref, alt = _u8(np.frombuffer(bytes(reference), dtype=np.uint8)), _u8(np.frombuffer(bytes(alternate), dtype=np.uint8))
+    n, m = len(ref[0]), len(alt[0])
+    cap = n + m + 8
+    ops, lens = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32)
+    cnt, off = C.c_int32(0), C.c_int32(0)
+    sw = np.zeros((n + 1, m + 1), dtype=np.int32) if matrices else None
+    bt = np.zeros((n + 1, m + 1), dtype=np.int32) if matrices else None
+    i32 = C.POINTER(C.c_int32)
+    rc = lib().oracle_sw_align(ref[1], n, alt[1], m, *[int(x) for x in parameters], strategy, ops.ctypes.data_as(i32), lens.ctypes.data_as(i32), cap,
+                               C.byref(cnt), C.byref(off), sw.ctypes.data_as(i32) if matrices else None, bt.ctypes.data_as(i32) if matrices else None)
+    cigar = "".join(f"{lens[k]}{'MIDS'[ops[k]]}" for k in range(cnt.value)) if rc == 0 else None
+    return (rc, cigar, off.value, sw, bt) if matrices else (rc, cigar, off.value)

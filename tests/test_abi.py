@@ -26,6 +26,16 @@ def test_header_symbols_are_exported():
     assert sorted(pairhmm.EXPORTS) == names
 
 
+def test_smith_waterman_header_symbols_are_exported():
+    text = open(os.path.join(ROOT, "include", "gatk_smithwaterman.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(gatk_sw_[a-z0-9_]+)\s*\(", text)))
+    assert names == ["gatk_sw_align", "gatk_sw_last_error"]
+    lib = pairhmm.load_library()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/gatk_smithwaterman.h but not exported"
+
+
 def test_version_string():
     assert b"gfx950" in pairhmm.load_library().gatk_pairhmm_version()
 
