@@ -12,8 +12,10 @@
 // and its length) cross lanes once per step with v_mov_b32_dpp wave_shr:1, and everything that flows
 // along a row (the cell to the left, the best horizontal gap and its length) stays in the lane's
 // registers.  The alternate sequence sits in LDS.  The back-track matrix goes to global memory as int16
-// (a gap is never longer than a sequence); a second kernel, one thread per pair, picks the end cell and
-// walks it.  The host reverses and consolidates the few CIGAR elements.
+// (a gap is never longer than a sequence) in the order it is produced, [step][row of the lane][lane], so
+// that the 64 lanes of a store write 128 consecutive bytes; a second kernel, one thread per pair, picks
+// the end cell and walks the matrix through the same index map.  The host reverses and consolidates the
+// few CIGAR elements.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -37,12 +39,12 @@ constexpr int kMatrixMinCutoff = -100000000;      // (int) -1e8, :233 (the stati
 
 struct PairDesc {
     int64_t ref_off, alt_off;      // byte offsets into the sequence pool
-    int64_t btrack_off;            // int16 offset of this pair's (n+1) x (m+1) back-track matrix
+    int64_t btrack_off;            // int16 offset of this pair's back-track matrix, [steps][rows_per_lane][64]
+    int32_t rows_per_lane;         // of the launch that fills it
     int64_t edge_off;              // int32 offset of its last-column (n+1) and bottom-row (m+1) scores
     int64_t elem_off;              // int32 offset of its raw CIGAR element list (2 ints per element)
     int32_t n, m;                  // reference / alternate length
     int32_t elem_cap;
-    int32_t reserved;
 };
 
 struct PairResult {
@@ -62,6 +64,13 @@ struct SwArgs {
     int32_t strategy;
 };
 
+// Where cell (i, j) of a pair's back-track matrix lives: lane t = (i - 1) / K reaches column j at step
+// j - 1 + t and holds row i as its row r = (i - 1) % K.
+__device__ __forceinline__ int64_t btrack_index(int i, int j, int K) {
+    const int t = (i - 1) / K, r = (i - 1) - t * K;
+    return (static_cast<int64_t>(j - 1 + t) * K + r) * kWave + t;
+}
+
 __device__ __forceinline__ int shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
 
 // First-row / first-column scores: gap penalties when overhangs count as indels (:244-261), else 0.
@@ -77,7 +86,7 @@ __global__ void __launch_bounds__(kWave) sw_fill(const SwArgs A, const int first
     if (pair_idx >= A.num_pairs) return;
     const PairDesc P = A.pairs[pair_idx];
     const int lane = threadIdx.x;
-    const int n = P.n, m = P.m, ncol = m + 1;
+    const int n = P.n, m = P.m;
     const uint8_t* ref = A.pool + P.ref_off;
     const uint8_t* alt = A.pool + P.alt_off;
     for (int x = lane; x < m + 2 * kWave; x += kWave) {
@@ -129,8 +138,8 @@ __global__ void __launch_bounds__(kWave) sw_fill(const SwArgs A, const int first
                 else if (bgh[r] >= bgv) { val = bgh[r]; btr = -gsh[r]; }
                 else { val = bgv; btr = gsv; }
                 val = val > kMatrixMinCutoff ? val : kMatrixMinCutoff;
+                bt[(static_cast<int64_t>(s) * K + r) * kWave + lane] = static_cast<int16_t>(btr);  // = btrack_index(i, j, K)
                 if (i <= n) {
-                    bt[static_cast<int64_t>(i) * ncol + j] = static_cast<int16_t>(btr);
                     if (j == m) last_col[i] = val;
                     if (i == n) bottom[j] = val;
                 }
@@ -149,7 +158,7 @@ __global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= A.num_pairs) return;
     const PairDesc P = A.pairs[k];
-    const int refLength = P.n, altLength = P.m, ncol = P.m + 1;
+    const int refLength = P.n, altLength = P.m;
     const int16_t* bt = A.btrack + P.btrack_off;
     const int32_t* last_col = A.edges + P.edge_off;
     const int32_t* bottom = last_col + (refLength + 1);
@@ -181,7 +190,7 @@ __global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A) {
     if (segment_length > 0 && A.strategy == GATK_SW_SOFTCLIP) { add(GATK_SW_OP_S, segment_length); segment_length = 0; }
     int state = GATK_SW_OP_M;
     do {
-        const int btr = bt[static_cast<int64_t>(p1) * ncol + p2];
+        const int btr = bt[btrack_index(p1, p2, P.rows_per_lane)];
         int new_state, step_length = 1;
         if (btr > 0) { new_state = GATK_SW_OP_D; step_length = btr; }
         else if (btr < 0) { new_state = GATK_SW_OP_I; step_length = -btr; }
@@ -291,13 +300,22 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
         P.n = n; P.m = m;
         P.ref_off = static_cast<int64_t>(pool_bytes); pool_bytes += align_up(n, 16);
         P.alt_off = static_cast<int64_t>(pool_bytes); pool_bytes += align_up(m, 16);
-        P.btrack_off = static_cast<int64_t>(bt_entries); bt_entries += align_up(static_cast<size_t>(n + 1) * (m + 1), 8);
+        max_n = std::max(max_n, n);
         P.edge_off = static_cast<int64_t>(edge_ints); edge_ints += static_cast<size_t>(n + 1) + (m + 1);
         // an element is added when the back-track changes state, plus a few at the ends: a list that outgrows
         // this cannot consolidate into cigar_capacity elements
         P.elem_cap = std::min(n + m + 8, 2 * cigar_capacity + 16);
         P.elem_off = static_cast<int64_t>(elem_ints); elem_ints += 2 * static_cast<size_t>(P.elem_cap);
-        max_n = std::max(max_n, n); max_m = std::max(max_m, m);
+        max_m = std::max(max_m, m);
+    }
+    // rows per lane: the smallest instantiation that holds the longest reference of the call
+    const int need = (max_n + kWave - 1) / kWave;
+    const int K = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 16 ? 16 : 32;
+    for (PairDesc& P : pairs) {
+        const size_t steps = static_cast<size_t>(P.m) + (P.n + K - 1) / K - 1;
+        P.rows_per_lane = K;
+        P.btrack_off = static_cast<int64_t>(bt_entries);
+        bt_entries += steps * K * kWave;
     }
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t at = off; off = align_up(off + bytes, 256); return at; };
@@ -329,15 +347,13 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
     A.num_pairs = num_pairs;
     A.w_match = parameters->w_match; A.w_mismatch = parameters->w_mismatch; A.w_open = parameters->w_open; A.w_extend = parameters->w_extend;
     A.strategy = overhang_strategy;
-    // rows per lane: the smallest instantiation that holds the longest reference of the call
     const size_t lds = static_cast<size_t>(max_m) + 2 * kWave;
-    const int need = (max_n + kWave - 1) / kWave;
     hipError_t e;
-    if (need <= 1) e = launch_fill<1>(A, num_pairs, lds, stream);
-    else if (need <= 2) e = launch_fill<2>(A, num_pairs, lds, stream);
-    else if (need <= 4) e = launch_fill<4>(A, num_pairs, lds, stream);
-    else if (need <= 8) e = launch_fill<8>(A, num_pairs, lds, stream);
-    else if (need <= 16) e = launch_fill<16>(A, num_pairs, lds, stream);
+    if (K == 1) e = launch_fill<1>(A, num_pairs, lds, stream);
+    else if (K == 2) e = launch_fill<2>(A, num_pairs, lds, stream);
+    else if (K == 4) e = launch_fill<4>(A, num_pairs, lds, stream);
+    else if (K == 8) e = launch_fill<8>(A, num_pairs, lds, stream);
+    else if (K == 16) e = launch_fill<16>(A, num_pairs, lds, stream);
     else e = launch_fill<32>(A, num_pairs, lds, stream);
     SW_TRY(e);
     hipLaunchKernelGGL(sw_backtrack, dim3((num_pairs + 63) / 64), dim3(64), 0, stream, A);
