@@ -8,6 +8,7 @@
 #include <emmintrin.h>
 
 #include <array>
+#include <functional>
 #include <thread>
 #include <atomic>
 #include <chrono>
@@ -418,6 +419,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     segs.reserve(static_cast<size_t>(total_reads));
     std::vector<int32_t> neg_inf_idx;
     std::vector<int> order, lens_desc;
+    std::vector<uint64_t> sort_keys;
     std::vector<ReadInfo> read_info(static_cast<size_t>(total_reads));
     std::vector<StreamDesc> stream_descs;
     bool any_hap_n = false, any_hap_other = false;
@@ -439,13 +441,14 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             if (!any_hap_other) scan_alphabet(b.hap_bases + o, len, any_hap_n, any_hap_other);
         }
         hap_max_all = std::max(hap_max_all, rp.hap_max);
-        order.clear();
+        sort_keys.clear();
         int read_max = 0;
         for (int r = 0; r < nr; ++r) {
             const int len = b.read_offsets[r + 1] - b.read_offsets[r];
             read_max = std::max(read_max, len);
             cells += static_cast<int64_t>(len) * hap_total;
-            if (len > 0) order.push_back(r);
+            // longest first, equal lengths in read order: one integer compare per step of the sort
+            if (len > 0) sort_keys.push_back((static_cast<uint64_t>(len) << 32) | static_cast<uint32_t>(~static_cast<uint32_t>(r)));
             else  // a zero-length read sums an empty last row: log10(0) (Log10PairHMM.java:128-134 on row 0)
                 for (int a = 0; a < nh; ++a)
                     neg_inf_idx.push_back(static_cast<int32_t>(R->region_out_off[k] + static_cast<int64_t>(r) * nh + a));
@@ -454,11 +457,13 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         rp.read_max = read_max;
         for (int r = 0; r < nr; ++r) read_info[rp.read_begin + r] = ReadInfo{rp.hap_begin, nh, -1, k};
         // wave-groups: longest reads first, filled lane segment by lane segment up to 64 lanes
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-            return (b.read_offsets[x + 1] - b.read_offsets[x]) > (b.read_offsets[y + 1] - b.read_offsets[y]);
-        });
+        std::sort(sort_keys.begin(), sort_keys.end(), std::greater<uint64_t>());
+        order.clear();
         lens_desc.clear();
-        for (int r : order) lens_desc.push_back(b.read_offsets[r + 1] - b.read_offsets[r]);
+        for (const uint64_t key : sort_keys) {
+            order.push_back(static_cast<int>(~static_cast<uint32_t>(key)));
+            lens_desc.push_back(static_cast<int>(key >> 32));
+        }
         // Rows per lane: one value for the region when the call is too small to fill the device (the model
         // then trades instruction count against waves in flight); otherwise every wave-group takes the
         // value that suits its own reads, so a region whose reads differ in length spreads over buckets.
