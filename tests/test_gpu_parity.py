@@ -504,3 +504,41 @@ def with_options_pipeline(hmm, pairs, fn):
         return fn()
     finally:
         hmm.set_option("pipeline_pairs", 131072)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PAIRHMM_FUZZ_SEEDS", "24"))))
+def test_random_shapes_and_options(hmm, oracle, seed):
+    """Seeded fuzz: random region shapes, quality models, wildcard rates and engine options; every result
+    within the bound of the oracle, and the fp64 passes within 1e-9."""
+    rng = np.random.default_rng(7000 + seed)
+    regions = []
+    for _ in range(int(rng.integers(1, 6))):
+        read_len = int(rng.choice([1, 7, 36, 76, 101, 151, 250, 400]))
+        hap_len = max(read_len, int(rng.choice([8, 60, 200, 420, 900])))
+        b = synth.make_batch(int(rng.integers(1, 70)), int(rng.integers(1, 40)), read_len, hap_len, seed=int(rng.integers(1 << 30)),
+                             len_jitter=int(rng.integers(0, read_len)), hap_len_jitter=int(rng.integers(0, max(1, hap_len // 3))),
+                             qual_model=str(rng.choice(["illumina", "uniform"])), gop_model=str(rng.choice(["const", "random"])),
+                             indel_rate=float(rng.choice([0.0, 0.0, 0.03])), n_rate=float(rng.choice([0.0, 0.001, 0.05])))
+        if rng.random() < 0.3:  # an 'N' in a haplotype
+            hb = b.hap_bases.copy()
+            hb[int(rng.integers(len(hb)))] = ord("N")
+            b = Batch(b.read_bases, b.read_quals, b.ins_gop, b.del_gop, b.gcp, b.read_offsets, hb, b.hap_offsets)
+        regions.append(b)
+    opts = {"stream_mode": int(rng.choice([-1, -1, 0])), "max_stream_haps": int(rng.choice([1, 3, 16])),
+            "emit_mode": int(rng.choice([-1, -1, 0]))}
+    if rng.random() < 0.4:
+        longest = max(int(np.diff(b.read_offsets).max()) for b in regions)
+        ks = [k for k in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16) if 64 * k >= longest + 2]
+        opts["force_rows_per_lane"] = int(rng.choice(ks))
+    hmm.set_option("pipeline_pairs", int(rng.choice([0, 200, 131072])))
+    try:
+        got = with_options(hmm, opts, lambda: hmm.compute_regions(regions))
+        hmm.set_option("fp32_threshold", 3e38)
+        got64 = with_options(hmm, opts, lambda: hmm.compute_regions(regions))
+    finally:
+        hmm.set_option("pipeline_pairs", 131072)
+        hmm.set_option("fp32_threshold", 1e-28)
+    for b, g, g64 in zip(regions, got, got64):
+        want = ref(oracle, b)
+        assert_parity(g, want)
+        assert_parity(g64, want, tol=1e-9)
