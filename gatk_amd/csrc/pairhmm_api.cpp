@@ -543,8 +543,10 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         bk.emit_mode = bk.emit_mode_fp64;
         if (!any_hap_other && h->emit_mode != 0) {
             const int lut = any_hap_n ? kEmitLut5 : kEmitLut4;
-            // the table must leave room for at least one workgroup per CU (64 KiB dynamic LDS per block)
-            if (lds_bytes_per_wave(K, lut, bk.max_hap_len) * kWavesPerBlock <= 64 * 1024) bk.emit_mode = lut;
+            // a workgroup's LDS must fit the 64 KiB a block may ask for; the stream pass keeps only the table
+            // there, the one-haplotype pass also the longest haplotype of the launch
+            const int lds = h->stream_mode != 0 ? stream_lds_bytes_per_wave(K, lut) : lds_bytes_per_wave(K, lut, bk.max_hap_len);
+            if (lds * kWavesPerBlock <= 64 * 1024) bk.emit_mode = lut;
         }
         // fp32 stream pass: the haplotype axis of every region is cut into runs; a run is as long as
         // keeps every wave slot of the device supplied twice over, so runs shrink towards the end of

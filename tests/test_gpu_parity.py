@@ -282,8 +282,10 @@ def test_long_haplotype_and_length_cap(hmm, oracle):
     acgt = np.frombuffer(b"ACGT", np.uint8)
     hap = acgt[rng.integers(0, 4, 16000)]
     read = hap[5000:5100].copy()
-    b = pack([(read, [30] * 100, None, None, None)], [hap])
-    assert_parity(hmm.compute_batch(b), ref(oracle, b, 1))
+    b = pack([(read, [30] * 100, None, None, None)], [hap, hap[:15000], hap[4000:9000]])
+    want = ref(oracle, b, 1)
+    assert_parity(hmm.compute_batch(b), want)                                              # haplotype runs
+    assert_parity(with_options(hmm, {"stream_mode": 0}, lambda: hmm.compute_batch(b)), want)  # one haplotype per item
     with pytest.raises(pairhmm.IllegalArgumentException):
         hmm.compute_batch(pack([(read, [30] * 100, None, None, None)], [acgt[rng.integers(0, 4, 16001)]]))
 
