@@ -121,7 +121,6 @@ public:
 
     gatk_pairhmm* handle() const { return h_; }
 
-private:
     static void check(int rc) {
         if (rc == GATK_PAIRHMM_OK) return;
         const std::string msg = gatk_pairhmm_last_error();
@@ -132,8 +131,82 @@ private:
             default: throw DeviceException(msg);
         }
     }
+private:
     gatk_pairhmm* h_ = nullptr;
     std::vector<double> mLikelihoodArray_;
+};
+
+// The likelihoods of one sample's reads against a region's alleles, kept on the device between the
+// PairHMM and the steps right behind it: the part of genotyper/ReadLikelihoods.java that works on the
+// values (normalizeLikelihoods :353, filterPoorlyModeledReads :1059, marginalize :911), for one region.
+class ResidentReadLikelihoods {
+public:
+    // Scores reads against alleles (PairHMM.computeLikelihoods) and keeps the result on the device.
+    ResidentReadLikelihoods(HipLoglessPairHMM& hmm, const std::vector<Bytes>& alleles, const std::vector<Read>& reads,
+                            const std::vector<Bytes>& gcp, int referenceAlleleIndex = -1)
+        : hmm_(hmm), alleles_(alleles.size()), reads_(reads.size()), reference_(referenceAlleleIndex) {
+        Bytes rb, rq, ri, rd, rg, hb;
+        std::vector<int32_t> ro{0}, ho{0};
+        for (size_t r = 0; r < reads.size(); ++r) {
+            const Read& x = reads[r];
+            rb.insert(rb.end(), x.bases.begin(), x.bases.end());
+            rq.insert(rq.end(), x.quals.begin(), x.quals.end());
+            ri.insert(ri.end(), x.insertionQuals.begin(), x.insertionQuals.end());
+            rd.insert(rd.end(), x.deletionQuals.begin(), x.deletionQuals.end());
+            rg.insert(rg.end(), gcp.at(r).begin(), gcp[r].end());
+            ro.push_back(static_cast<int32_t>(rb.size()));
+        }
+        for (const Bytes& a : alleles) { hb.insert(hb.end(), a.begin(), a.end()); ho.push_back(static_cast<int32_t>(hb.size())); }
+        for (Bytes* v : {&rb, &rq, &ri, &rd, &rg, &hb}) v->push_back(0);
+        gatk_pairhmm_batch b{static_cast<int32_t>(reads.size()), static_cast<int32_t>(alleles.size()), rb.data(), rq.data(), ri.data(),
+                             rd.data(), rg.data(), ro.data(), hb.data(), ho.data(), nullptr};
+        HipLoglessPairHMM::check(gatk_pairhmm_upload(hmm.handle(), 1, &b, &r_));
+        HipLoglessPairHMM::check(gatk_pairhmm_compute_resident(hmm.handle(), r_, 1));
+    }
+    ~ResidentReadLikelihoods() { if (r_) gatk_pairhmm_resident_free(hmm_.handle(), r_); }
+    ResidentReadLikelihoods(const ResidentReadLikelihoods&) = delete;
+    ResidentReadLikelihoods& operator=(const ResidentReadLikelihoods&) = delete;
+
+    // ReadLikelihoods.normalizeLikelihoods, genotyper/ReadLikelihoods.java:353
+    void normalizeLikelihoods(bool bestToZero, double maximumLikelihoodDifferenceCap) {
+        HipLoglessPairHMM::check(gatk_pairhmm_normalize_resident(hmm_.handle(), r_, &reference_, bestToZero ? 1 : 0, maximumLikelihoodDifferenceCap));
+    }
+    // The reads ReadLikelihoods.filterPoorlyModeledReads would remove, :1059 (true = poorly modelled).
+    std::vector<bool> poorlyModeledReads(double maximumErrorPerBase) {
+        std::vector<uint8_t> f(reads_);
+        uint8_t* p = f.data();
+        HipLoglessPairHMM::check(gatk_pairhmm_poorly_modeled_resident(hmm_.handle(), r_, maximumErrorPerBase, &p));
+        return std::vector<bool>(f.begin(), f.end());
+    }
+    // ReadLikelihoods.marginalize through an old-to-new allele index map (-1: dropped), :911-939.
+    LikelihoodMatrix marginalize(const std::vector<int32_t>& oldToNewAlleleIndex, std::vector<Bytes> newAlleles) {
+        if (oldToNewAlleleIndex.size() != alleles_) throw IllegalArgumentException("one new index per old allele is required");
+        const int32_t n_new = static_cast<int32_t>(newAlleles.size());
+        std::vector<double> out(reads_ * newAlleles.size());
+        const int32_t* mp = oldToNewAlleleIndex.data();
+        double* op = out.data();
+        HipLoglessPairHMM::check(gatk_pairhmm_marginalize_resident(hmm_.handle(), r_, &mp, &n_new, &op));
+        LikelihoodMatrix m(std::move(newAlleles), reads_);
+        for (size_t r = 0; r < reads_; ++r)
+            for (int32_t a = 0; a < n_new; ++a) m.set(a, r, out[r * n_new + a]);
+        return m;
+    }
+    // values[allele][read] as they stand on the device
+    LikelihoodMatrix matrix(std::vector<Bytes> alleles) {
+        std::vector<double> out(reads_ * alleles_);
+        double* op = out.data();
+        HipLoglessPairHMM::check(gatk_pairhmm_download(hmm_.handle(), r_, &op));
+        LikelihoodMatrix m(std::move(alleles), reads_);
+        for (size_t r = 0; r < reads_; ++r)
+            for (size_t a = 0; a < alleles_; ++a) m.set(a, r, out[r * alleles_ + a]);
+        return m;
+    }
+
+private:
+    HipLoglessPairHMM& hmm_;
+    gatk_pairhmm_resident* r_ = nullptr;
+    size_t alleles_, reads_;
+    int32_t reference_;
 };
 
 }  // namespace gatk

@@ -1,10 +1,12 @@
-// Exercises the C++ host mirror (include/gatk_pairhmm.hpp) end to end on GPU 0: the closed-form
-// single-base answers, the read-major array, an error path and the BatchPairHMM interface.
+// Exercises the C++ host mirrors (include/gatk_pairhmm.hpp, include/gatk_smithwaterman.hpp) end to end on
+// GPU 0: the closed-form single-base answers, the read-major array, an error path, the BatchPairHMM
+// interface, the ReadLikelihoods steps on resident results and three Smith-Waterman cases.
 // Prints "cxx_driver ok" and exits 0 when everything matches.
 #include <cmath>
 #include <cstdio>
 
 #include "gatk_pairhmm.hpp"
+#include "gatk_smithwaterman.hpp"
 
 static gatk::Bytes B(const char* s) { return gatk::Bytes(s, s + std::char_traits<char>::length(s)); }
 
@@ -32,6 +34,31 @@ int main() {
         const auto res = hmm.batchGetResult();
         if (res.size() != 2 || std::fabs(res[0] - want[0]) > 1e-6 || std::fabs(res[1] - want[2]) > 1e-6) { std::printf("batch mismatch\n"); return 1; }
         hmm.finalizeRegion();
+        {
+            // the steps behind the path on resident results: alleles A (reference), C, AC against reads A and C
+            const std::vector<gatk::Bytes> alleles = {B("A"), B("C"), B("AC")};
+            gatk::ResidentReadLikelihoods rl(hmm, alleles, reads, {{10}, {10}}, 0);
+            const auto before = rl.matrix(alleles);
+            for (int a = 0; a < 3; ++a)
+                if (before.get(a, 0) != m.get(a, 0) || before.get(a, 1) != m.get(a, 1)) { std::printf("resident matrix differs\n"); return 1; }
+            const auto merged = rl.marginalize({0, 1, 1}, {B("A"), B("C")});
+            if (merged.get(0, 0) != m.get(0, 0) || merged.get(1, 0) != std::fmax(m.get(1, 0), m.get(2, 0))) { std::printf("marginalize mismatch\n"); return 1; }
+            const auto poorly = rl.poorlyModeledReads(0.02);  // one-base reads: threshold -4
+            if (poorly[0] || poorly[1]) { std::printf("poorly-modelled flags mismatch\n"); return 1; }
+            rl.normalizeLikelihoods(true, -1.0);
+            const auto after = rl.matrix(alleles);
+            // read 0: best alternative is AC (-0.347): cap -1.347 lifts C (-3.52); best overall A -> 0
+            if (after.get(0, 0) != 0.0 || std::fabs(after.get(1, 0) - (m.get(2, 0) - 1.0 - m.get(0, 0))) > 1e-12 ||
+                std::fabs(after.get(2, 0) - (m.get(2, 0) - m.get(0, 0))) > 1e-12) { std::printf("normalize mismatch\n"); return 1; }
+        }
+        {
+            const gatk::SWPairwiseAlignment del(B("AAAAACCCCCGGGGG"), B("AAAAAGGGGG"));
+            if (del.getCigar() != "5M5D5M" || del.getAlignmentStart2wrt1() != 0) { std::printf("SW deletion case: %s\n", del.getCigar().c_str()); return 1; }
+            const gatk::SWPairwiseAlignment inner(B("TTTTACGTACGTTTTT"), B("ACGTACGT"));
+            if (inner.getCigar() != "8M" || inner.getAlignmentStart2wrt1() != 4) { std::printf("SW offset case\n"); return 1; }
+            const gatk::SWPairwiseAlignment over(B("ACGTACGT"), B("GGACGTACGTGG"), gatk::STANDARD_NGS, gatk::OverhangStrategy::INDEL);
+            if (over.getCigar() != "2I8M2I") { std::printf("SW overhang case: %s\n", over.getCigar().c_str()); return 1; }
+        }
         hmm.close();
     } catch (const std::exception& e) {
         std::printf("exception: %s\n", e.what());
