@@ -30,16 +30,13 @@ hipError_t launch_forward(const DeviceBatch& B, int rows_per_lane, int emit_mode
 int lds_bytes_per_wave(int rows_per_lane, int emit_mode, int max_hap_len);
 int stream_lds_bytes_per_wave(int rows_per_lane, int emit_mode);
 hipError_t launch_stream(const DeviceBatch& B, int rows_per_lane, int emit_mode, hipStream_t stream);
-hipError_t launch_expand_haps(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_finish_stream(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int blocks, hipStream_t stream);
 hipError_t launch_normalize_reads(const DeviceBatch& B, const int32_t* reference_allele_index, int best_to_zero, double cap, hipStream_t stream);
 hipError_t launch_flag_poorly_modelled_reads(const DeviceBatch& B, double maximum_error_per_base, uint8_t* flags, hipStream_t stream);
 hipError_t launch_marginalize_reads(const DeviceBatch& B, const int32_t* old_to_new, const int64_t* new_base, const int32_t* new_count,
                                     double* new_out, hipStream_t stream);
-hipError_t launch_validate(const DeviceBatch& B, hipStream_t stream);
-hipError_t launch_expand_reads(const DeviceBatch& B, hipStream_t stream);
-hipError_t launch_fill_neg_inf(double* out, const int32_t* idx, int n, hipStream_t stream);
+hipError_t launch_prepare(const DeviceBatch& B, bool expand_rows, bool stream, hipStream_t s);
 }  // namespace pairhmm_hip
 
 using namespace pairhmm_hip;
@@ -107,6 +104,8 @@ struct PinnedBuf {
     }
 };
 
+constexpr size_t kCounterBytes = 256;  // device counters of a pass: error word, rerun-list lengths, pair-list lengths
+
 struct Bucket {
     int rows_per_lane = 0;
     int task_begin = 0;   // offset of this bucket in the rerun-list array
@@ -141,7 +140,10 @@ struct gatk_pairhmm_resident {
     double plan_ms = 0, upload_ms = 0;
     // ---- device ----
     DevBuf d_arena;  // every input array of the call, one H2D copy
-    DevBuf d_out, d_rerun_lists, d_counters;
+    // d_out: [kCounterBytes of counters][likelihoods]: one device-to-host copy fetches both
+    DevBuf d_out, d_rerun_lists;
+    int32_t* counters() const { return d_out.as<int32_t>(); }
+    double* out() const { return reinterpret_cast<double*>(d_out.as<uint8_t>() + kCounterBytes); }
     DevBuf d_row_consts;  // fp32 row constants of every read, written on the device
     DevBuf d_hap_stream, d_raw_out, d_pair_lists;  // fp32 stream pass and the fp64 pair pass behind it
     size_t hap_stream_entries = 0;
@@ -152,14 +154,18 @@ struct gatk_pairhmm_resident {
     bool any_stream = false;
     bool streamed = false;  // the last pass enqueued used the stream pass and the fp64 pair pass
     DeviceBatch base{};  // pointers into d_arena
-    const int32_t* d_neg_inf_idx = nullptr;
+    bool counters_clear = false;        // the counters were zeroed behind the last download: the next pass need not
+    hipEvent_t ev_downloaded = nullptr; // recorded behind a download's device-to-host copy
     // HIP events of the passes enqueued since the last wait (timing option): start, forward kernels
     // begin / end, fp64 pass begin, end
     using EventSet = std::array<hipEvent_t, 5>;
     std::vector<EventSet> ev_pending, ev_free;
     gatk_pairhmm_stats last_timing{};
     void release() {
-        for (DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_counters, &d_row_consts, &d_hap_stream, &d_raw_out, &d_pair_lists, &d_epilogue}) b->release();
+        for (DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_row_consts, &d_hap_stream, &d_raw_out, &d_pair_lists, &d_epilogue}) b->release();
+        counters_clear = false;
+        if (ev_downloaded) (void)hipEventDestroy(ev_downloaded);
+        ev_downloaded = nullptr;
         for (auto* v : {&ev_pending, &ev_free}) {
             for (auto& set : *v)
                 for (auto& e : set)
@@ -191,6 +197,8 @@ struct gatk_pairhmm {
     hipStream_t stream2 = nullptr;
     int64_t pipeline_pairs = 131072;  // pairs per part of such a call; 0: never split a call
     PinnedBuf stage_in, stage_out;  // pinned staging shared by every upload / download on this handle
+    hipEvent_t stage_in_copied = nullptr;  // recorded behind the host-to-device copy out of stage_in
+    bool stage_in_busy = false;
     std::vector<double> likelihood_array;
     gatk_pairhmm_stats stats{};
     // BatchPairHMM queue: one single-read region per batchAdd
@@ -661,6 +669,10 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
                  o_rg = have_gcp ? o_rg_up : L.add(rbytes + 16);
 
     HIP_TRY(hipSetDevice(h->device));
+    if (h->stage_in_busy) {  // the previous upload's copy out of the staging buffer
+        HIP_TRY(hipEventSynchronize(h->stage_in_copied));
+        h->stage_in_busy = false;
+    }
     HIP_TRY(h->stage_in.ensure(upload_bytes));
     uint8_t* S = static_cast<uint8_t*>(h->stage_in.p);
     int32_t* roff = reinterpret_cast<int32_t*>(S + o_roff);
@@ -726,9 +738,10 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     if (!R->stream) R->stream = h->stream;
     hipStream_t s = R->stream;
     HIP_TRY(R->d_arena.ensure(L.size));
-    HIP_TRY(R->d_out.ensure(std::max<size_t>(static_cast<size_t>(call_pairs) * sizeof(double), 16)));
+    const void* const out_before = R->d_out.p;
+    HIP_TRY(R->d_out.ensure(kCounterBytes + std::max<size_t>(static_cast<size_t>(call_pairs) * sizeof(double), 16)));
+    if (R->d_out.p != out_before) R->counters_clear = false;
     HIP_TRY(R->d_rerun_lists.ensure(std::max<size_t>(static_cast<size_t>(total_tasks) * sizeof(int32_t), 16)));
-    HIP_TRY(R->d_counters.ensure(256));
     HIP_TRY(R->d_row_consts.ensure((rbytes + 2 * static_cast<size_t>(total_reads) + 2) * sizeof(RowConst)));
     if (R->any_stream) {
         HIP_TRY(R->d_hap_stream.ensure(R->hap_stream_entries * sizeof(uint16_t)));
@@ -764,9 +777,13 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     B.pair_lists = R->d_pair_lists.as<RerunPair>();
     for (size_t bi = 0; bi < R->buckets.size(); ++bi) B.bucket_pair_begin[bi] = static_cast<int32_t>(R->buckets[bi].pair_begin);
     B.row_consts = R->d_row_consts.as<RowConst>();
-    R->d_neg_inf_idx = reinterpret_cast<const int32_t*>(D + o_neg);
-    // the staging buffer is reused by the next upload on this handle: finish the copy first
-    HIP_TRY(hipStreamSynchronize(s));
+    B.neg_inf_idx = reinterpret_cast<const int32_t*>(D + o_neg);
+    B.num_neg_inf = R->num_neg_inf;
+    B.hap_stream_len = static_cast<int32_t>(R->hap_stream_entries);
+    // the staging buffer is reused by the next upload on this handle: that upload waits for this copy
+    if (!h->stage_in_copied) HIP_TRY(hipEventCreateWithFlags(&h->stage_in_copied, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->stage_in_copied, s));
+    h->stage_in_busy = true;
     R->plan_ms = t_planned - t_begin;
     R->upload_ms = now_ms() - t_planned;
     return GATK_PAIRHMM_OK;
@@ -790,23 +807,18 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
         R->ev_pending.push_back(ev);
         HIP_TRY(hipEventRecord(ev[0], s));
     }
-    HIP_TRY(hipMemsetAsync(R->d_counters.p, 0, 256, s));
+    if (!R->counters_clear) HIP_TRY(hipMemsetAsync(R->counters(), 0, kCounterBytes, s));
+    R->counters_clear = false;
     DeviceBatch B = R->base;
     B.err_prob = h->d_err;
     B.match_to_match = h->d_mm;
-    B.out = R->d_out.as<double>();
-    B.error_word = R->d_counters.as<int32_t>();
+    B.out = R->out();
+    B.error_word = R->counters();
     B.fp32_threshold = h->fp32_threshold;
     B.squash_base_quals = h->squash_base_quals ? 1 : 0;
-    HIP_TRY(launch_validate(B, s));
-    B.pair_counts = R->d_counters.as<int32_t>() + 1 + kMaxBuckets;
+    B.pair_counts = R->counters() + 1 + kMaxBuckets;
     const bool streaming = R->any_stream && !h->force_fp64;
-    if (!h->force_fp64) HIP_TRY(launch_expand_reads(B, s));
-    if (streaming) {
-        HIP_TRY(hipMemsetAsync(B.hap_stream, 0, R->hap_stream_entries * sizeof(uint16_t), s));
-        HIP_TRY(launch_expand_haps(B, s));
-    }
-    if (R->num_neg_inf > 0) HIP_TRY(launch_fill_neg_inf(B.out, R->d_neg_inf_idx, R->num_neg_inf, s));
+    HIP_TRY(launch_prepare(B, !h->force_fp64, streaming, s));
     if (timing) HIP_TRY(hipEventRecord(ev[1], s));
     auto bucket_args = [&](size_t bi, int mode) {
         const Bucket& bk = R->buckets[bi];
@@ -814,7 +826,7 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
         L.region_descs = B.region_descs + bk.desc_begin;
         L.num_region_descs = bk.num_descs;
         L.num_tasks = bk.num_tasks;
-        L.rerun_count = R->d_counters.as<int32_t>() + 1 + bi;
+        L.rerun_count = R->counters() + 1 + bi;
         L.rerun_list = R->d_rerun_lists.as<int32_t>() + bk.task_begin;
         L.lds_per_wave = lds_bytes_per_wave(bk.rows_per_lane, mode, bk.max_hap_len);
         return L;
@@ -870,12 +882,19 @@ int group_of_task(const gatk_pairhmm_resident* R, const Bucket& bk, int task) {
     return d.group_begin + (task - d.task_begin) % d.num_groups;
 }
 
+int digest_counters(gatk_pairhmm* h, gatk_pairhmm_resident* R, const int32_t* counters);
+
 // Wait for the stream, turn the device error word into the reference's exception code, fill stats.
 int finish_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(R->stream));
     int32_t counters[1 + 2 * kMaxBuckets] = {0};
-    HIP_TRY(hipMemcpy(counters, R->d_counters.p, sizeof counters, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(counters, R->counters(), sizeof counters, hipMemcpyDeviceToHost));
+    return digest_counters(h, R, counters);
+}
+
+// The stream is idle and `counters` is the host copy of the pass's counters: stats and error code.
+int digest_counters(gatk_pairhmm* h, gatk_pairhmm_resident* R, const int32_t* counters) {
     gatk_pairhmm_stats st{};
     st.pairs = R->total_pairs;
     st.cells = R->cells;
@@ -926,23 +945,34 @@ int finish_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
 }
 
 int download_into(gatk_pairhmm* h, gatk_pairhmm_resident* R, double* const* outs) {
-    if (int rc = finish_compute(h, R)) return rc;
-    if (R->total_pairs == 0) return GATK_PAIRHMM_OK;
+    if (R->total_pairs == 0) return finish_compute(h, R);
     int with_output = 0, last = -1;
     for (int k = 0; k < R->num_regions; ++k) {
         if (R->region_out_off[k + 1] == R->region_out_off[k]) continue;
-        if (!outs || !outs[k]) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "likelihoods cannot be null");
+        if (!outs || !outs[k]) {
+            (void)finish_compute(h, R);
+            return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "likelihoods cannot be null");
+        }
         ++with_output; last = k;
     }
     const size_t bytes = static_cast<size_t>(R->total_pairs) * sizeof(double);
-    if (with_output == 1) {  // straight into the caller's array
-        HIP_TRY(hipMemcpy(outs[last], R->d_out.p, bytes, hipMemcpyDeviceToHost));
+    if (with_output == 1 && bytes > (size_t{256} << 10)) {  // a large single matrix: straight into the caller's array
+        if (int rc = finish_compute(h, R)) return rc;
+        HIP_TRY(hipMemcpy(outs[last], R->out(), bytes, hipMemcpyDeviceToHost));
         return GATK_PAIRHMM_OK;
     }
-    // many regions: one device-to-host copy into pinned memory, then scatter on the host
-    HIP_TRY(h->stage_out.ensure(bytes));
-    HIP_TRY(hipMemcpy(h->stage_out.p, R->d_out.p, bytes, hipMemcpyDeviceToHost));
-    const double* src = static_cast<const double*>(h->stage_out.p);
+    // counters and likelihoods in one device-to-host copy into pinned memory, one wait, then scatter on the host
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(h->stage_out.ensure(kCounterBytes + bytes));
+    HIP_TRY(hipMemcpyAsync(h->stage_out.p, R->d_out.p, kCounterBytes + bytes, hipMemcpyDeviceToHost, R->stream));
+    // the host waits for the copy only; the counters are zeroed for the next pass behind it
+    if (!R->ev_downloaded) HIP_TRY(hipEventCreateWithFlags(&R->ev_downloaded, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(R->ev_downloaded, R->stream));
+    HIP_TRY(hipMemsetAsync(R->counters(), 0, kCounterBytes, R->stream));
+    R->counters_clear = true;
+    HIP_TRY(hipEventSynchronize(R->ev_downloaded));
+    if (int rc = digest_counters(h, R, static_cast<const int32_t*>(h->stage_out.p))) return rc;
+    const double* src = reinterpret_cast<const double*>(static_cast<const uint8_t*>(h->stage_out.p) + kCounterBytes);
     for (int k = 0; k < R->num_regions; ++k) {
         const int64_t n = R->region_out_off[k + 1] - R->region_out_off[k];
         if (n > 0) memcpy(outs[k], src + R->region_out_off[k], static_cast<size_t>(n) * sizeof(double));
@@ -1224,6 +1254,7 @@ int gatk_pairhmm_close(gatk_pairhmm* h) {
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     h->scratch.release();
     h->scratch2.release();
+    if (h->stage_in_copied) { (void)hipEventSynchronize(h->stage_in_copied); (void)hipEventDestroy(h->stage_in_copied); }
     h->stage_in.release();
     h->stage_out.release();
     if (h->d_err) (void)hipFree(h->d_err);
@@ -1325,7 +1356,7 @@ int check_epilogue(gatk_pairhmm* h, gatk_pairhmm_resident* r) {
 }
 DeviceBatch epilogue_batch(gatk_pairhmm_resident* r) {
     DeviceBatch B = r->base;
-    B.out = r->d_out.as<double>();
+    B.out = r->out();
     return B;
 }
 }  // namespace
@@ -1425,7 +1456,7 @@ int gatk_pairhmm_marginalize_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r,
 
 int gatk_pairhmm_resident_device_output(gatk_pairhmm_resident* r, void** device_ptr, int64_t* count) {
     if (!r || !device_ptr || !count) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "argument cannot be null");
-    *device_ptr = r->d_out.p;
+    *device_ptr = r->out();
     *count = r->total_pairs;
     return GATK_PAIRHMM_OK;
 }

@@ -135,6 +135,7 @@ struct DeviceBatch {
     // fp32 stream pass
     uint16_t* hap_stream;          // table offsets (base code * 512) of every haplotype, one zero entry between neighbours
     const int32_t* hap_stream_off; // [num_haps] index of a haplotype's first base in hap_stream
+    int32_t hap_stream_len;        // entries of hap_stream, pads included
     const StreamDesc* stream_descs;
     int32_t num_stream_descs;
     float* raw_out;                // [pairs] scaled likelihood sums, laid out like out
@@ -157,6 +158,8 @@ struct DeviceBatch {
     float fp32_threshold;
     int32_t lds_per_wave;          // bytes of LDS each wave owns
     int64_t total_read_bytes;
+    const int32_t* neg_inf_idx;    // [num_neg_inf] indices in out[] of the pairs of zero-length reads
+    int32_t num_neg_inf;
 };
 
 }  // namespace pairhmm_hip

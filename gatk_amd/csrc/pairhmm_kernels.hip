@@ -720,17 +720,22 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_stream(const Device
 #endif
 }
 
-// Haplotype bytes -> table offsets in the stream (the gaps and pads were zeroed beforehand).
-__global__ void __launch_bounds__(256) expand_haps(const DeviceBatch B) {
-    const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (a >= B.num_haps) return;
+// Haplotype a -> table offsets in the stream, by one wave, which also zeroes the entries between the
+// previous haplotype and this one (gaps, or the front pad) and, behind the last haplotype, the rest
+// of the stream: every entry of the stream is written by exactly one wave.
+__device__ __forceinline__ void expand_hap(const DeviceBatch& B, const int a, const int lane) {
     const uint8_t* src = B.hap_pool + B.hap_off[a];
-    uint16_t* dst = B.hap_stream + B.hap_stream_off[a];
+    const int begin = B.hap_stream_off[a];
     const int len = B.hap_len[a];
-    for (int j = threadIdx.x & 63; j < len; j += kWave) {
+    const int prev_end = a == 0 ? 0 : B.hap_stream_off[a - 1] + B.hap_len[a - 1];
+    for (int j = prev_end + lane; j < begin; j += kWave) B.hap_stream[j] = 0;
+    uint16_t* dst = B.hap_stream + begin;
+    for (int j = lane; j < len; j += kWave) {
         const unsigned byte = src[j];
         dst[j] = static_cast<uint16_t>((byte == 'N' ? 4u : ((byte >> 1) & 3u)) * kLutCodeStride);
     }
+    if (a == B.num_haps - 1)
+        for (int j = begin + len + lane; j < B.hap_stream_len; j += kWave) B.hap_stream[j] = 0;
 }
 
 // Raw sums of the stream pass -> log10 likelihoods; pairs fp32 could not hold go on their bucket's
@@ -995,24 +1000,28 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_list(const DeviceBa
     }
 }
 
-// Read expansion for the fp32 pass: one wave per read, one lane per RowConst entry.  The arithmetic
-// is done in double and rounded once, so an entry holds exactly what the forward kernel would have
-// derived from the quality bytes (PairHMMModel.java:109-143 for the transitions,
-// QualityUtils.java:169-176 for the priors).
-__global__ void __launch_bounds__(256) expand_reads(const DeviceBatch B) {
-    const int read = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (read >= B.num_reads) return;
-    const int lane = threadIdx.x & 63;
+// Read r, by one wave: the checks the reference makes while expanding a read's qualities
+// (PairHMMModel.java:136-138: negative ins/del/GCP byte -> IllegalArgumentException;
+// QualityUtils.java:173: base quality 255 indexes past the 255-entry cache) and, when `expand` is
+// set, the RowConst entries of the fp32 pass, one lane per entry.  The arithmetic is done in double
+// and rounded once, so an entry holds exactly what the forward kernel would have derived from the
+// quality bytes (PairHMMModel.java:109-143 for the transitions, QualityUtils.java:169-176 for the
+// priors).
+__device__ __forceinline__ void prepare_read(const DeviceBatch& B, const int read, const int lane, const bool expand) {
     const int ro = B.read_off[read];
     const int R = B.read_off[read + 1] - ro;
     RowConst* dst = B.row_consts + ro + 2 * static_cast<int64_t>(read);
+    int bad = 0;
     for (int i = lane; i <= R + 1; i += kWave) {
         RowConst c{0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, kNoBase, 0u};
         double t2 = 0.0, t4 = 1.0;  // a pad row hands its deletion mass down unweighted
         if (i >= 1 && i <= R) {
             const unsigned x = B.read_bases[ro + i - 1];
+            const unsigned ins_byte = B.ins_gop[ro + i - 1], del_byte = B.del_gop[ro + i - 1], gcp_byte = B.gcp[ro + i - 1];
+            if ((ins_byte | del_byte | gcp_byte) & 0x80u) bad |= 1;
+            if (B.read_quals[ro + i - 1] == 255) bad |= 2;
             const double e = B.err_prob[effective_qual(B, ro + i - 1, read)];
-            const unsigned ins = B.ins_gop[ro + i - 1] & 127u, del = B.del_gop[ro + i - 1] & 127u;
+            const unsigned ins = ins_byte & 127u, del = del_byte & 127u;
             const double t0 = B.match_to_match[ins * 128u + del];
             const double p = 1.0 - e;
             const double q = (x == 'N') ? p : e / 3.0;  // a read 'N' matches every base
@@ -1020,7 +1029,7 @@ __global__ void __launch_bounds__(256) expand_reads(const DeviceBatch B) {
             t4 = B.err_prob[del];
             c.p_match = static_cast<float>(p * t0);
             c.p_mismatch = static_cast<float>(q * t0);
-            c.t5 = static_cast<float>(B.err_prob[B.gcp[ro + i - 1]]);
+            c.t5 = static_cast<float>(B.err_prob[gcp_byte]);
             c.base = x;
         }
         if (i < R) {  // transitions of read row i + 1, taken from quals[i]
@@ -1038,28 +1047,32 @@ __global__ void __launch_bounds__(256) expand_reads(const DeviceBatch B) {
         } else {
             c.p_match = c.p_mismatch = 1.0f;  // sum row
         }
-        dst[i] = c;
-    }
-}
-
-// Input validation: the checks the reference makes while expanding a read's qualities
-// (PairHMMModel.java:136-138: negative ins/del/GCP byte -> IllegalArgumentException;
-// QualityUtils.java:173: base quality 255 indexes past the 255-entry cache).
-__global__ void __launch_bounds__(256) validate_quals(const DeviceBatch B) {
-    const int64_t n = B.total_read_bytes;
-    int bad = 0;
-    for (int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n;
-         k += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        if ((B.ins_gop[k] | B.del_gop[k] | B.gcp[k]) & 0x80) bad |= 1;
-        if (B.read_quals[k] == 255) bad |= 2;
+        if (expand) dst[i] = c;
     }
     if (bad) atomicOr(B.error_word, bad);
 }
 
-// Zero-length reads: the last matrix row is row 0, whose M and I are all zero -> log10(0).
-__global__ void __launch_bounds__(256) fill_neg_inf(double* out, const int32_t* idx, int n) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) out[idx[k]] = -__builtin_inf();
+// Everything a pass needs before its forward kernels, in one launch.  Blocks [0, read_blocks) take
+// four reads each (prepare_read), blocks [read_blocks, read_blocks + hap_blocks) four haplotypes each
+// (expand_hap), the rest the pairs of zero-length reads: the last matrix row is row 0, whose M and I
+// are all zero -> log10(0).
+__global__ void __launch_bounds__(256) prepare_batch(const DeviceBatch B, const int read_blocks, const int hap_blocks, const int expand) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int block = blockIdx.x;
+    if (block < read_blocks) {
+        const int read = block * 4 + wave;
+        if (read < B.num_reads) prepare_read(B, read, lane, expand != 0);
+        return;
+    }
+    block -= read_blocks;
+    if (block < hap_blocks) {
+        const int a = block * 4 + wave;
+        if (a < B.num_haps) expand_hap(B, a, lane);
+        return;
+    }
+    block -= hap_blocks;
+    const int k = block * 256 + threadIdx.x;
+    if (k < B.num_neg_inf) B.out[B.neg_inf_idx[k]] = -__builtin_inf();
 }
 
 template <typename T, int K, int MODE>
@@ -1182,12 +1195,6 @@ hipError_t launch_marginalize_reads(const DeviceBatch& B, const int32_t* old_to_
     return hipGetLastError();
 }
 
-hipError_t launch_expand_haps(const DeviceBatch& B, hipStream_t stream) {
-    if (B.num_haps <= 0) return hipSuccess;
-    hipLaunchKernelGGL(expand_haps, dim3((B.num_haps + 3) / 4), dim3(256), 0, stream, B);
-    return hipGetLastError();
-}
-
 hipError_t launch_finish_stream(const DeviceBatch& B, hipStream_t stream) {
     if (B.num_reads <= 0) return hipSuccess;
     hipLaunchKernelGGL(finish_stream, dim3((B.num_reads + 3) / 4), dim3(256), 0, stream, B);
@@ -1211,23 +1218,14 @@ hipError_t launch_forward(const DeviceBatch& B, int rows_per_lane, int emit_mode
                 : launch_t<float>(B, rows_per_lane, emit_mode, list_mode, blocks, stream);
 }
 
-hipError_t launch_fill_neg_inf(double* out, const int32_t* idx, int n, hipStream_t stream) {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fill_neg_inf, dim3((n + 255) / 256), dim3(256), 0, stream, out, idx, n);
-    return hipGetLastError();
-}
-
-hipError_t launch_expand_reads(const DeviceBatch& B, hipStream_t stream) {
-    if (B.num_reads <= 0) return hipSuccess;
-    hipLaunchKernelGGL(expand_reads, dim3((B.num_reads + 3) / 4), dim3(256), 0, stream, B);
-    return hipGetLastError();
-}
-
-hipError_t launch_validate(const DeviceBatch& B, hipStream_t stream) {
-    if (B.total_read_bytes <= 0) return hipSuccess;
-    int64_t blocks = (B.total_read_bytes + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(validate_quals, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, B);
+// expand_rows: write the RowConst entries (the fp32 passes read them); stream: fill the haplotype stream.
+hipError_t launch_prepare(const DeviceBatch& B, bool expand_rows, bool stream, hipStream_t s) {
+    const int read_blocks = (B.num_reads + 3) / 4;
+    const int hap_blocks = stream ? (B.num_haps + 3) / 4 : 0;
+    const int neg_blocks = (B.num_neg_inf + 255) / 256;
+    const int blocks = read_blocks + hap_blocks + neg_blocks;
+    if (blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(prepare_batch, dim3(blocks), dim3(256), 0, s, B, read_blocks, hap_blocks, expand_rows ? 1 : 0);
     return hipGetLastError();
 }
 
