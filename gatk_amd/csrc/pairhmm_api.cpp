@@ -179,6 +179,7 @@ struct gatk_pairhmm {
     int device = 0;
     hipStream_t stream = nullptr;
     int wave_slots = 3072;  // waves the device holds at once at three per SIMD
+    int stream_lds_floor = 0;  // least LDS bytes per wave of the stream pass (caps the waves a CU holds)
     double* d_err = nullptr;
     double* d_mm = nullptr;
     bool initialized = false;
@@ -839,7 +840,7 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
             L.stream_descs = B.stream_descs + bk.stream_desc_begin;
             L.num_stream_descs = bk.num_stream_descs;
             L.num_tasks = bk.num_stream_tasks;
-            L.lds_per_wave = stream_lds_bytes_per_wave(bk.rows_per_lane, mode);
+            L.lds_per_wave = std::max(stream_lds_bytes_per_wave(bk.rows_per_lane, mode), h->stream_lds_floor);
             HIP_TRY(launch_stream(L, bk.rows_per_lane, mode, s));
             continue;
         }
@@ -1284,6 +1285,8 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
     else if (n == "stream_mode") h->stream_mode = static_cast<int>(value);
     else if (n == "squash_base_quals") h->squash_base_quals = value != 0;
     else if (n == "pipeline_pairs") h->pipeline_pairs = std::max<int64_t>(0, static_cast<int64_t>(value));
+    else if (n == "wave_slots") h->wave_slots = std::max(64, static_cast<int>(value));
+    else if (n == "stream_lds_floor") h->stream_lds_floor = std::max(0, static_cast<int>(value));
     else if (n == "max_stream_haps") h->max_stream_haps = std::max(1, static_cast<int>(value));
     else return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "unknown option " + n);
     return GATK_PAIRHMM_OK;

@@ -688,6 +688,7 @@ __device__ __forceinline__ void run_stream(const DeviceBatch& B, const int task_
 #pragma unroll
                     for (int r = 0; r < K; ++r) pc[u][r] = pn[u][r];
             }
+            PHASE_END(3);
         } else {
             masked_step(s0, codes.x & 0xffffu);
             masked_step(s0 + 1, codes.x >> 16);
@@ -695,6 +696,7 @@ __device__ __forceinline__ void run_stream(const DeviceBatch& B, const int task_
             masked_step(s0 + 3, codes.y >> 16);
             advance_codes(q);
             ++q;
+            PHASE_END(2);
         }
     }
     PHASE_END(3);

@@ -157,8 +157,11 @@ int gatk_pairhmm_device_count(int32_t* count);
  * work item), "max_stream_haps" (longest run, 1..16), "squash_base_quals" (1 = base qualities under 18 count as 6, see
  * gatk_pairhmm_batch), "pipeline_pairs" (default 131072: a compute_regions call with more
  * pairs is cut between regions into parts of about that many pairs, and one part is planned and copied while
- * the kernels of the part before it run; 0 = never cut).  Planning options take effect at the next
- * upload or host-pointer call. */
+ * the kernels of the part before it run; 0 = never cut), and two knobs for occupancy experiments:
+ * "wave_slots" (waves the planner assumes the device holds at once, default 12 per CU) and
+ * "stream_lds_floor" (least bytes of LDS a wave of the fp32 stream pass asks for; a larger value
+ * lowers the number of waves a CU holds).  Planning options take effect at the next upload or
+ * host-pointer call. */
 int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value);
 
 /*

@@ -25,8 +25,8 @@ res.compute()
 dll.gatk_pairhmm_debug_phase_clocks(out, 1)
 if out[7]:
     print(f"wave lifetime: {out[4]} shader ticks / {out[7]} ticks of the 100 MHz counter -> {100.0 * out[4] / out[7]:.0f} MHz")
-names = ["decode+hap image", "row constants+table", "fill", "steady", "drain", "termination"]
-tot = sum(out[:6])
+names = ["decode+gap list", "row constants+table", "blocks with a lane at a gap", "steady blocks"]
+tot = sum(out[:4])  # slot 4 is the wave lifetime, which the four phases add up to
 print(f"tasks {out[6]}  cycles/task {tot / max(out[6], 1):.0f}  kernel_ms {hmm.stats()['fp32_kernel_ms']:.3f}")
-for n, v in zip(names, out[:6]):
-    print(f"  {n:22s} {100.0 * v / tot:5.1f} %   {v / max(out[6], 1):9.0f} cycles/task")
+for n, v in zip(names, out[:4]):
+    print(f"  {n:28s} {100.0 * v / tot:5.1f} %   {v / max(out[6], 1):9.0f} cycles/task")
