@@ -1,0 +1,199 @@
+// Stress driver for the C-ABI's host code, meant to be built with the host side under AddressSanitizer and
+// UndefinedBehaviorSanitizer (tools/build_stress_asan.sh) and run on a GPU.  It pushes randomly shaped region
+// batches (empty regions, zero-length reads, missing optional arrays, 'N' bases, mapping-quality caps, a few
+// reads that underflow fp32) through every entry point and checks that differently planned engine
+// configurations agree: automatic planning against forced rows per lane with one haplotype per work item,
+// one big call against region-at-a-time calls, host-pointer calls against the resident path.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../include/gatk_pairhmm.h"
+
+namespace {
+
+struct Rng {
+    uint64_t s;
+    uint32_t next() { s = s * 6364136223846793005ull + 1442695040888963407ull; return static_cast<uint32_t>(s >> 33); }
+    int range(int lo, int hi) { return lo + static_cast<int>(next() % static_cast<uint32_t>(hi - lo + 1)); }  // inclusive
+};
+
+struct Region {
+    std::vector<uint8_t> rb, rq, ri, rd, rg, hb, mapq;
+    std::vector<int32_t> roff{0}, hoff{0};
+    bool with_ins, with_del, with_gcp, with_mapq;
+    gatk_pairhmm_batch c{};
+    void finish() {
+        c.num_reads = static_cast<int32_t>(roff.size()) - 1;
+        c.num_haps = static_cast<int32_t>(hoff.size()) - 1;
+        c.read_bases = rb.data(); c.read_quals = rq.data();
+        c.ins_gop = with_ins ? ri.data() : nullptr;
+        c.del_gop = with_del ? rd.data() : nullptr;
+        c.gcp = with_gcp ? rg.data() : nullptr;
+        c.read_offsets = roff.data();
+        c.hap_bases = hb.data(); c.hap_offsets = hoff.data();
+        c.read_mapq = with_mapq ? mapq.data() : nullptr;
+    }
+};
+
+Region make_region(Rng& g, bool allow_empty) {
+    static const char letters[] = "ACGT";
+    Region r;
+    r.with_ins = g.range(0, 3) != 0; r.with_del = g.range(0, 3) != 0; r.with_gcp = g.range(0, 3) != 0; r.with_mapq = g.range(0, 4) == 0;
+    const int span = g.range(30, 500);
+    std::vector<uint8_t> ref(span);
+    for (auto& b : ref) b = letters[g.range(0, 3)];
+    const int nh = g.range(1, 20);
+    for (int a = 0; a < nh; ++a) {
+        std::vector<uint8_t> h = ref;
+        for (int e = g.range(0, 4); e > 0; --e) {
+            const int p = g.range(0, static_cast<int>(h.size()) - 1);
+            switch (g.range(0, 3)) {
+                case 0: h[p] = letters[g.range(0, 3)]; break;
+                case 1: h.insert(h.begin() + p, letters[g.range(0, 3)]); break;
+                case 2: if (h.size() > 12) h.erase(h.begin() + p); break;
+                default: if (g.range(0, 9) == 0) h[p] = 'N';
+            }
+        }
+        r.hb.insert(r.hb.end(), h.begin(), h.end());
+        r.hoff.push_back(static_cast<int32_t>(r.hb.size()));
+    }
+    const int nr = allow_empty && g.range(0, 15) == 0 ? 0 : g.range(1, 90);
+    for (int k = 0; k < nr; ++k) {
+        const int len = g.range(0, 30) == 0 ? 0 : g.range(1, std::min(span, g.range(0, 5) == 0 ? 260 : 151));
+        const int start = g.range(0, span - std::max(len, 1));
+        const bool noisy = g.range(0, 25) == 0;  // many errors at high quality: the fp32 sum underflows
+        for (int i = 0; i < len; ++i) {
+            uint8_t b = ref[start + i];
+            if (g.range(0, noisy ? 2 : 60) == 0) b = letters[g.range(0, 3)];
+            if (g.range(0, 400) == 0) b = 'N';
+            r.rb.push_back(b);
+            r.rq.push_back(static_cast<uint8_t>(noisy ? g.range(35, 41) : g.range(2, 41)));
+            r.ri.push_back(static_cast<uint8_t>(g.range(0, 8) == 0 ? g.range(1, 45) : 45));
+            r.rd.push_back(static_cast<uint8_t>(g.range(0, 8) == 0 ? g.range(1, 45) : 45));
+            r.rg.push_back(static_cast<uint8_t>(g.range(0, 8) == 0 ? g.range(5, 20) : 10));
+        }
+        r.roff.push_back(static_cast<int32_t>(r.rb.size()));
+        r.mapq.push_back(static_cast<uint8_t>(g.range(10, 60)));
+    }
+    r.finish();
+    return r;
+}
+
+#define CHECK(call)                                                                          \
+    do {                                                                                     \
+        const int rc_ = (call);                                                              \
+        if (rc_ != 0) { std::printf("%s -> %d: %s\n", #call, rc_, gatk_pairhmm_last_error()); return 1; } \
+    } while (0)
+
+double worst_difference(const std::vector<std::vector<double>>& a, const std::vector<std::vector<double>>& b) {
+    double worst = 0.0;
+    for (size_t k = 0; k < a.size(); ++k)
+        for (size_t i = 0; i < a[k].size(); ++i) {
+            if (std::isinf(a[k][i]) || std::isinf(b[k][i])) {
+                if (a[k][i] != b[k][i]) return INFINITY;
+                continue;
+            }
+            if (std::isnan(a[k][i]) || std::isnan(b[k][i])) return INFINITY;
+            worst = std::fmax(worst, std::fabs(a[k][i] - b[k][i]));
+        }
+    return worst;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const int num_regions = argc > 1 ? std::atoi(argv[1]) : 400;
+    const uint64_t seed = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 7;
+    Rng g{seed};
+    std::vector<Region> regions;
+    regions.reserve(num_regions);
+    for (int k = 0; k < num_regions; ++k) regions.push_back(make_region(g, true));
+    for (auto& r : regions) r.finish();  // pointers into the vectors after the moves
+    std::vector<gatk_pairhmm_batch> batches;
+    int64_t pairs = 0;
+    for (auto& r : regions) { batches.push_back(r.c); pairs += static_cast<int64_t>(r.c.num_reads) * r.c.num_haps; }
+    auto outputs = [&]() {
+        std::vector<std::vector<double>> o(regions.size());
+        for (size_t k = 0; k < regions.size(); ++k) o[k].assign(static_cast<size_t>(regions[k].c.num_reads) * regions[k].c.num_haps, NAN);
+        return o;
+    };
+    auto pointers = [](std::vector<std::vector<double>>& o) {
+        std::vector<double*> p;
+        for (auto& v : o) p.push_back(v.empty() ? nullptr : v.data());
+        return p;
+    };
+
+    gatk_pairhmm* h = nullptr;
+    CHECK(gatk_pairhmm_create(0, &h));
+    CHECK(gatk_pairhmm_set_option(h, "pipeline_pairs", 20000));  // several parts: the pipelined path
+    auto all = outputs();
+    { auto p = pointers(all); CHECK(gatk_pairhmm_compute_regions(h, num_regions, batches.data(), p.data())); }
+
+    // region at a time, one haplotype per work item, forced rows per lane
+    gatk_pairhmm* h2 = nullptr;
+    CHECK(gatk_pairhmm_create(0, &h2));
+    CHECK(gatk_pairhmm_set_option(h2, "stream_mode", 0));
+    CHECK(gatk_pairhmm_set_option(h2, "force_rows_per_lane", 5));
+    auto single = outputs();
+    for (int k = 0; k < num_regions; ++k)
+        CHECK(gatk_pairhmm_compute_likelihoods(h2, &batches[k], single[k].empty() ? nullptr : single[k].data()));
+    const double d1 = worst_difference(all, single);
+
+    // resident path with everything in fp64
+    gatk_pairhmm* h3 = nullptr;
+    CHECK(gatk_pairhmm_create(0, &h3));
+    CHECK(gatk_pairhmm_set_option(h3, "force_fp64", 1));
+    gatk_pairhmm_resident* res = nullptr;
+    CHECK(gatk_pairhmm_upload(h3, num_regions, batches.data(), &res));
+    CHECK(gatk_pairhmm_compute_resident(h3, res, 0));
+    CHECK(gatk_pairhmm_compute_resident(h3, res, 1));
+    auto fp64 = outputs();
+    { auto p = pointers(fp64); CHECK(gatk_pairhmm_download(h3, res, p.data())); }
+    const double d2 = worst_difference(all, fp64);
+    // the steps behind the path, on the resident results
+    std::vector<std::vector<uint8_t>> flags(regions.size());
+    std::vector<uint8_t*> flag_ptrs;
+    for (size_t k = 0; k < regions.size(); ++k) { flags[k].assign(regions[k].c.num_reads, 2); flag_ptrs.push_back(flags[k].empty() ? nullptr : flags[k].data()); }
+    CHECK(gatk_pairhmm_poorly_modeled_resident(h3, res, 0.02, flag_ptrs.data()));
+    std::vector<std::vector<int32_t>> maps(regions.size());
+    std::vector<const int32_t*> map_ptrs;
+    std::vector<int32_t> new_counts;
+    auto merged = outputs();
+    for (size_t k = 0; k < regions.size(); ++k) {
+        const int nh = regions[k].c.num_haps, n_new = std::max(1, nh / 2);
+        for (int a = 0; a < nh; ++a) maps[k].push_back(g.range(-1, n_new - 1));
+        map_ptrs.push_back(maps[k].data());
+        new_counts.push_back(n_new);
+        merged[k].assign(static_cast<size_t>(regions[k].c.num_reads) * n_new, NAN);
+    }
+    { auto p = pointers(merged); CHECK(gatk_pairhmm_marginalize_resident(h3, res, map_ptrs.data(), new_counts.data(), p.data())); }
+    CHECK(gatk_pairhmm_normalize_resident(h3, res, nullptr, 1, -4.5));
+    CHECK(gatk_pairhmm_resident_free(h3, res));
+
+    // the queueing interface and the single-pair call on the first region that has a read
+    for (auto& r : regions) {
+        if (r.c.num_reads == 0 || r.roff[1] == 0 || !r.with_ins || !r.with_del || !r.with_gcp) continue;
+        std::vector<const uint8_t*> hp;
+        std::vector<int32_t> hl;
+        for (int a = 0; a < r.c.num_haps; ++a) { hp.push_back(r.hb.data() + r.hoff[a]); hl.push_back(r.hoff[a + 1] - r.hoff[a]); }
+        CHECK(gatk_pairhmm_batch_add(h, r.c.num_haps, hp.data(), hl.data(), r.rb.data(), r.rq.data(), r.ri.data(), r.rd.data(), r.rg.data(), r.roff[1]));
+        const double* got = nullptr;
+        int64_t count = 0;
+        CHECK(gatk_pairhmm_batch_get_result(h, &got, &count));
+        if (count != r.c.num_haps) { std::printf("batch_get_result count %lld\n", static_cast<long long>(count)); return 1; }
+        double one = 0.0;
+        CHECK(gatk_pairhmm_compute_pair(h, hp[0], hl[0], r.rb.data(), r.rq.data(), r.ri.data(), r.rd.data(), r.rg.data(), r.roff[1], &one));
+        if (std::fabs(one - got[0]) > 1e-3) { std::printf("pair call differs from the queue: %g vs %g\n", one, got[0]); return 1; }
+        break;
+    }
+    CHECK(gatk_pairhmm_close(h));
+    CHECK(gatk_pairhmm_close(h2));
+    CHECK(gatk_pairhmm_close(h3));
+    std::printf("regions %d pairs %lld: pipelined vs region-at-a-time max |d| %.3g, vs fp64 %.3g\n", num_regions, static_cast<long long>(pairs), d1, d2);
+    if (!(d1 <= 2e-3) || !(d2 <= 1e-3)) { std::printf("FAILED\n"); return 1; }
+    std::printf("ok\n");
+    return 0;
+}
