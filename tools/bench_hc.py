@@ -41,9 +41,9 @@ def score(regions, device, chunk, workers):
         arr = (C.c_void_p * len(idx))(*[outs[i].ctypes.data if outs[i].size else None for i in idx])
         calls.append((len(idx), cbs, arr))
     handles = [HipLoglessPairHMM(device) for _ in range(workers)]
-    for h in handles:  # an engine in steady state: buffers grown to the size of these calls, clocks up
-        n, cbs, arr = calls[0]
-        assert lib.gatk_pairhmm_compute_regions(h._h, n, cbs, arr) == 0
+    for h in handles:  # an engine in steady state: buffers grown to the largest of these calls, clocks up
+        for n, cbs, arr in (calls if workers > 1 else calls[:1]):
+            assert lib.gatk_pairhmm_compute_regions(h._h, n, cbs, arr) == 0
     nxt = [0]
     lock = threading.Lock()
     errors = []
