@@ -101,11 +101,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the PairHMM engine has no CPU path")
+    # Rehearsal of the multi-rank path on a box with fewer GPUs than ranks: GATK_BENCH_BACKEND=gloo keeps the
+    # two reductions on the host and lets ranks share a device.  The driver's runs use RCCL, one rank per GPU.
+    backend = os.environ.get("GATK_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    reduce_device = "cuda" if backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from gatk_amd import synth
     from gatk_amd.pairhmm import HipLoglessPairHMM
@@ -135,10 +144,10 @@ def main():
     fp32_ms, fp64_ms, aux_ms = st["fp32_kernel_ms"], st["fp64_kernel_ms"], st["aux_kernel_ms"]
     rerun_pairs = st["rerun_pairs"] * args.steps  # every pass scores the same batch
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([float(batch.cells)], dtype=torch.float64, device="cuda")
+        c = torch.tensor([float(batch.cells)], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total_cells = float(c.item())
     else:
