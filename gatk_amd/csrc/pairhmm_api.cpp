@@ -179,6 +179,7 @@ struct gatk_pairhmm {
     int device = 0;
     hipStream_t stream = nullptr;
     int wave_slots = 3072;  // waves the device holds at once at three per SIMD
+    bool pipeline_ramp = true;  // the first two parts of a cut call are a quarter and a half of pipeline_pairs
     int stream_lds_floor = 0;  // least LDS bytes per wave of the stream pass (caps the waves a CU holds)
     double* d_err = nullptr;
     double* d_mm = nullptr;
@@ -284,37 +285,36 @@ int choose_group_rows_per_lane(int longest) {
 }
 
 int check_region(const gatk_pairhmm_batch& b, int k) {
-    char where[64];
-    snprintf(where, sizeof where, " (region %d)", k);
-    if (b.num_reads < 0 || b.num_haps < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("negative read or haplotype count") + where);
+    const auto where = [k] { return " (region " + std::to_string(k) + ")"; };  // built only for a failure
+    if (b.num_reads < 0 || b.num_haps < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("negative read or haplotype count") + where());
     if (b.num_reads == 0) return GATK_PAIRHMM_OK;  // PairHMM.java:193
     if (!b.read_offsets || !b.read_bases || !b.read_quals)  // insertion / deletion / GCP arrays may be null: defaults
-        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("readBases cannot be null") + where);
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("readBases cannot be null") + where());
     int read_max = 0, hap_max = 0;
     for (int r = 0; r < b.num_reads; ++r) {
         const int len = b.read_offsets[r + 1] - b.read_offsets[r];
-        if (len < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("read offsets must not decrease") + where);
+        if (len < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("read offsets must not decrease") + where());
         read_max = std::max(read_max, len);
     }
     if (b.num_haps > 0 && (!b.hap_offsets || !b.hap_bases))
-        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("haplotypeBases cannot be null") + where);
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("haplotypeBases cannot be null") + where());
     for (int a = 0; a < b.num_haps; ++a) {
         const int len = b.hap_offsets[a + 1] - b.hap_offsets[a];
-        if (len < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("haplotype offsets must not decrease") + where);
+        if (len < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("haplotype offsets must not decrease") + where());
         hap_max = std::max(hap_max, len);
     }
     // PairHMM.initialize, reached through PairHMM.java:200-201
-    if (read_max <= 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "READ_MAX_LENGTH must be > 0 but got " + std::to_string(read_max) + where);
-    if (hap_max <= 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "HAPLOTYPE_MAX_LENGTH must be > 0 but got " + std::to_string(hap_max) + where);
+    if (read_max <= 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "READ_MAX_LENGTH must be > 0 but got " + std::to_string(read_max) + where());
+    if (hap_max <= 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "HAPLOTYPE_MAX_LENGTH must be > 0 but got " + std::to_string(hap_max) + where());
     for (int a = 0; a < b.num_haps; ++a)
         if (b.hap_offsets[a + 1] - b.hap_offsets[a] == 0)
-            return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("zero-length haplotype: the reference result is undefined") + where);
+            return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("zero-length haplotype: the reference result is undefined") + where());
     if (read_max > kWave * kMaxRowsPerLane - 2)
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "readBases is too long, got " + std::to_string(read_max) + " but max is " +
-                                                       std::to_string(kWave * kMaxRowsPerLane - 2) + where);
+                                                       std::to_string(kWave * kMaxRowsPerLane - 2) + where());
     if (hap_max > kMaxHapLen)
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "Haplotype bases is too long, got " + std::to_string(hap_max) + " but max is " +
-                                                       std::to_string(kMaxHapLen) + where);
+                                                       std::to_string(kMaxHapLen) + where());
     return GATK_PAIRHMM_OK;
 }
 
@@ -390,6 +390,8 @@ struct RegionPlan {
     int group_begin = 0, num_groups = 0;
     int hap_max = 0, cost = 0;
     int read_max = 0;
+    int longest = 0;      // longest read in this plan's wave-groups
+    int seg_reads = 0;    // reads in them
 };
 
 int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, const gatk_pairhmm_batch* regions) {
@@ -427,8 +429,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     std::vector<SegDesc> segs;
     segs.reserve(static_cast<size_t>(total_reads));
     std::vector<int32_t> neg_inf_idx;
-    std::vector<int> order, lens_desc;
-    std::vector<uint64_t> sort_keys;
+    std::vector<int> order, lens_desc, len_slot;
     std::vector<ReadInfo> read_info(static_cast<size_t>(total_reads));
     std::vector<StreamDesc> stream_descs;
     bool any_hap_n = false, any_hap_other = false;
@@ -450,28 +451,42 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             if (!any_hap_other) scan_alphabet(b.hap_bases + o, len, any_hap_n, any_hap_other);
         }
         hap_max_all = std::max(hap_max_all, rp.hap_max);
-        sort_keys.clear();
-        int read_max = 0;
+        int read_max = 0, read_min = std::numeric_limits<int>::max(), nonempty = 0;
+        int64_t len_total = 0;
         for (int r = 0; r < nr; ++r) {
             const int len = b.read_offsets[r + 1] - b.read_offsets[r];
-            read_max = std::max(read_max, len);
-            cells += static_cast<int64_t>(len) * hap_total;
-            // longest first, equal lengths in read order: one integer compare per step of the sort
-            if (len > 0) sort_keys.push_back((static_cast<uint64_t>(len) << 32) | static_cast<uint32_t>(~static_cast<uint32_t>(r)));
-            else  // a zero-length read sums an empty last row: log10(0) (Log10PairHMM.java:128-134 on row 0)
+            len_total += len;
+            read_info[rp.read_begin + r] = ReadInfo{rp.hap_begin, nh, -1, k};
+            if (len > 0) {
+                read_max = std::max(read_max, len);
+                read_min = std::min(read_min, len);
+                ++nonempty;
+            } else {  // a zero-length read sums an empty last row: log10(0) (Log10PairHMM.java:128-134 on row 0)
                 for (int a = 0; a < nh; ++a)
                     neg_inf_idx.push_back(static_cast<int32_t>(R->region_out_off[k] + static_cast<int64_t>(r) * nh + a));
+            }
         }
+        cells += len_total * hap_total;
         read_max_all = std::max(read_max_all, read_max);
         rp.read_max = read_max;
-        for (int r = 0; r < nr; ++r) read_info[rp.read_begin + r] = ReadInfo{rp.hap_begin, nh, -1, k};
-        // wave-groups: longest reads first, filled lane segment by lane segment up to 64 lanes
-        std::sort(sort_keys.begin(), sort_keys.end(), std::greater<uint64_t>());
-        order.clear();
-        lens_desc.clear();
-        for (const uint64_t key : sort_keys) {
-            order.push_back(static_cast<int>(~static_cast<uint32_t>(key)));
-            lens_desc.push_back(static_cast<int>(key >> 32));
+        // wave-groups: longest reads first (equal lengths in read order), filled lane segment by lane segment
+        // up to 64 lanes.  Lengths are small integers: a counting sort.
+        order.assign(static_cast<size_t>(nonempty), 0);
+        lens_desc.assign(static_cast<size_t>(nonempty), 0);
+        if (nonempty > 0) {
+            len_slot.assign(static_cast<size_t>(read_max - read_min + 2), 0);
+            for (int r = 0; r < nr; ++r) {
+                const int len = b.read_offsets[r + 1] - b.read_offsets[r];
+                if (len > 0) ++len_slot[read_max - len + 1];  // slot 0: the longest
+            }
+            for (size_t i = 1; i < len_slot.size(); ++i) len_slot[i] += len_slot[i - 1];
+            for (int r = 0; r < nr; ++r) {
+                const int len = b.read_offsets[r + 1] - b.read_offsets[r];
+                if (len <= 0) continue;
+                const int at = len_slot[read_max - len]++;
+                order[at] = r;
+                lens_desc[at] = len;
+            }
         }
         // Rows per lane: one value for the region when the call is too small to fill the device (the model
         // then trades instruction count against waves in flight); otherwise every wave-group takes the
@@ -487,6 +502,8 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
                 rp.group_begin = static_cast<int>(groups.size());
                 rp.num_groups = 0;
                 rp.cost = 0;
+                rp.longest = lens_desc[pos];
+                rp.seg_reads = 0;
                 plans.push_back(rp);
             }
             GroupDesc g{static_cast<int32_t>(segs.size()), 0, 0};
@@ -497,6 +514,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
                 const int seg = (len + 1 + K) / K;  // rows >= len + 2: a pad row in front, the sum row behind
                 if (used + seg > kWave) break;
                 segs.push_back(SegDesc{rp.read_begin + r, static_cast<uint8_t>(used), static_cast<uint8_t>(seg), static_cast<uint16_t>(len)});
+                read_info[rp.read_begin + r].rows_per_lane = K;
                 used += seg;
                 max_seg = std::max(max_seg, seg);
                 ++g.num_segs; ++pos;
@@ -505,6 +523,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             groups.push_back(g);
             R->group_segs.push_back(static_cast<uint8_t>(g.num_segs));
             ++plans.back().num_groups;
+            plans.back().seg_reads += g.num_segs;
             plans.back().cost = std::max(plans.back().cost, rp.hap_max + max_seg - 1);
         }
         read_cursor += nr;
@@ -520,11 +539,17 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
 
     // ---- buckets: one launch per rows-per-lane value; longest work items first -----------------
     std::vector<int> by_cost(plans.size());
-    std::iota(by_cost.begin(), by_cost.end(), 0);
-    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int x, int y) {
-        return plans[x].K != plans[y].K ? plans[x].K < plans[y].K : plans[x].cost > plans[y].cost;
-    });
+    {
+        // rows per lane ascending, cost descending, plan order on ties: one integer key per plan
+        std::vector<uint64_t> keys(plans.size());
+        for (size_t i = 0; i < plans.size(); ++i)
+            keys[i] = (static_cast<uint64_t>(plans[i].K) << 52) | (static_cast<uint64_t>(0xFFFFF - std::min(plans[i].cost, 0xFFFFF)) << 32) | i;
+        std::sort(keys.begin(), keys.end());
+        for (size_t i = 0; i < keys.size(); ++i) by_cost[i] = static_cast<int>(keys[i] & 0xFFFFFFFFu);
+    }
     int64_t total_tasks = 0, stream_pairs = 0;
+    int8_t stream_bucket_of_rows[sizeof(DeviceBatch::stream_bucket_of_rows)];
+    memset(stream_bucket_of_rows, -1, sizeof stream_bucket_of_rows);
     for (size_t i = 0; i < by_cost.size();) {
         const int K = plans[by_cost[i]].K;
         Bucket bk;
@@ -594,13 +619,10 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             int read_max = 1;
             for (size_t j = bucket_first; j < i; ++j) {
                 const RegionPlan& rp = plans[by_cost[j]];
-                for (int g = rp.group_begin; g < rp.group_begin + rp.num_groups; ++g)
-                    for (int x = groups[g].seg_begin; x < groups[g].seg_begin + groups[g].num_segs; ++x) {
-                        read_info[segs[x].read_idx].bucket = bucket_index;  // zero-length reads are in no segment
-                        read_max = std::max<int>(read_max, segs[x].read_len);
-                        bk.num_pairs += rp.nh;
-                    }
+                read_max = std::max(read_max, rp.longest);
+                bk.num_pairs += static_cast<int64_t>(rp.seg_reads) * rp.nh;
             }
+            stream_bucket_of_rows[K] = static_cast<int8_t>(bucket_index);
             // The pair pass picks its own rows per lane: at most 8 (more spills in double), the value that
             // wastes the fewest lane-rows for the bucket's longest read, the smaller one on a tie (the
             // pass usually has too few pairs to fill the device, so a short sweep matters more than
@@ -777,6 +799,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     B.raw_out = R->d_raw_out.as<float>();
     B.pair_lists = R->d_pair_lists.as<RerunPair>();
     for (size_t bi = 0; bi < R->buckets.size(); ++bi) B.bucket_pair_begin[bi] = static_cast<int32_t>(R->buckets[bi].pair_begin);
+    memcpy(B.stream_bucket_of_rows, stream_bucket_of_rows, sizeof stream_bucket_of_rows);
     B.row_consts = R->d_row_consts.as<RowConst>();
     B.neg_inf_idx = reinterpret_cast<const int32_t*>(D + o_neg);
     B.num_neg_inf = R->num_neg_inf;
@@ -867,6 +890,12 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
         }
     }
     if (timing) HIP_TRY(hipEventRecord(ev[4], s));
+    // Hand the queued work to the device now: the runtime may otherwise hold launches back until the
+    // host next waits on this stream, which in an overlapped call is only after the next part has been planned.
+    {
+        const hipError_t q = hipStreamQuery(s);
+        if (q != hipSuccess && q != hipErrorNotReady) HIP_TRY(q);
+    }
     R->streamed = streaming;
     R->computed = true;
     return GATK_PAIRHMM_OK;
@@ -1052,13 +1081,19 @@ int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gat
                                  double* const* likelihoods) {
     if (int rc = check_handle(h)) return rc;
     if (num_regions < 0 || (num_regions > 0 && !regions)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "regions cannot be null");
-    // parts of about pipeline_pairs pairs, cut between regions
+    // parts of about pipeline_pairs pairs, cut between regions; the first two are a quarter and a half of that,
+    // so that the device starts early (nothing overlaps the planning of the first part)
     std::vector<int> cuts{0};
     if (h->pipeline_pairs > 0) {
-        int64_t acc = 0;
+        int64_t acc = 0, total = 0;
+        for (int k = 0; k < num_regions; ++k)
+            if (regions[k].num_reads > 0 && regions[k].num_haps > 0) total += static_cast<int64_t>(regions[k].num_reads) * regions[k].num_haps;
+        const bool ramp = h->pipeline_ramp && total >= 3 * h->pipeline_pairs;
         for (int k = 0; k < num_regions; ++k) {
             if (regions[k].num_reads > 0 && regions[k].num_haps > 0) acc += static_cast<int64_t>(regions[k].num_reads) * regions[k].num_haps;
-            if (acc >= h->pipeline_pairs && k + 1 < num_regions) { cuts.push_back(k + 1); acc = 0; }
+            const size_t part = cuts.size() - 1;
+            const int64_t want = !ramp || part >= 2 ? h->pipeline_pairs : h->pipeline_pairs >> (2 - part);
+            if (acc >= want && k + 1 < num_regions) { cuts.push_back(k + 1); acc = 0; }
         }
     }
     cuts.push_back(num_regions);
@@ -1285,6 +1320,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
     else if (n == "stream_mode") h->stream_mode = static_cast<int>(value);
     else if (n == "squash_base_quals") h->squash_base_quals = value != 0;
     else if (n == "pipeline_pairs") h->pipeline_pairs = std::max<int64_t>(0, static_cast<int64_t>(value));
+    else if (n == "pipeline_ramp") h->pipeline_ramp = value != 0;
     else if (n == "wave_slots") h->wave_slots = std::max(64, static_cast<int>(value));
     else if (n == "stream_lds_floor") h->stream_lds_floor = std::max(0, static_cast<int>(value));
     else if (n == "max_stream_haps") h->max_stream_haps = std::max(1, static_cast<int>(value));

@@ -91,7 +91,7 @@ struct StreamDesc {
 struct ReadInfo {
     int32_t hap_begin;   // global index of the first haplotype of the read's region
     int32_t num_haps;    // haplotypes of the read's region
-    int32_t bucket;      // launch bucket of the region, or -1 when the stream pass did not score the read
+    int32_t rows_per_lane;  // rows per lane of the read's wave-group (which names its launch bucket), -1 for a zero-length read
     int32_t region;      // index of the read's region among the call's regions
 };
 
@@ -143,6 +143,7 @@ struct DeviceBatch {
     int32_t* pair_counts;          // [kMaxBuckets] pairs queued for the fp64 pair pass
     RerunPair* pair_lists;         // their lists, bucket b starting at bucket_pair_begin[b]
     int32_t bucket_pair_begin[kMaxBuckets];
+    int8_t stream_bucket_of_rows[20];  // launch bucket of the stream pass by rows per lane, -1 when there is none
     // fp64 pair pass of one bucket
     const int32_t* pair_count;     // = pair_counts + bucket
     const RerunPair* pair_list;    // = pair_lists + bucket_pair_begin[bucket]

@@ -746,10 +746,11 @@ __global__ void __launch_bounds__(256) finish_stream(const DeviceBatch B) {
     const int read = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (read >= B.num_reads) return;
     const ReadInfo info = B.read_info[read];
-    if (info.bucket < 0) return;
+    const int bucket = info.rows_per_lane < 0 ? -1 : B.stream_bucket_of_rows[info.rows_per_lane];
+    if (bucket < 0) return;  // the stream pass did not score this read
     const int ob = B.read_out_base[read];
     const int lane = threadIdx.x & 63;
-    RerunPair* const list = B.pair_lists + B.bucket_pair_begin[info.bucket];
+    RerunPair* const list = B.pair_lists + B.bucket_pair_begin[bucket];
     for (int a0 = 0; a0 < info.num_haps; a0 += kWave) {  // wave-uniform trip count
         const int a = a0 + lane;
         bool push = false;
@@ -762,7 +763,7 @@ __global__ void __launch_bounds__(256) finish_stream(const DeviceBatch B) {
         if (pushing != 0) {
             const int leader = __ffsll(static_cast<long long>(pushing)) - 1;
             int base = 0;
-            if (lane == leader) base = atomicAdd(&B.pair_counts[info.bucket], __popcll(pushing));
+            if (lane == leader) base = atomicAdd(&B.pair_counts[bucket], __popcll(pushing));
             base = __shfl(base, leader);
             if (push) list[base + __popcll(pushing & ((1ull << lane) - 1ull))] = RerunPair{read, a};
         }
