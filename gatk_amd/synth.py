@@ -100,7 +100,7 @@ def config_c5(seed=DEFAULT_SEED, num_reads=1024, num_haps=32):
     return make_batch(num_reads, num_haps, 250, 1000, seed=seed, indel_rate=0.04, mean_qual=20.0, gop_model="random")
 
 
-def make_regions(num_regions, seed=DEFAULT_SEED, coverage=30, read_len=151):
+def make_regions(num_regions, seed=DEFAULT_SEED, coverage=30, read_len=151, read_len_jitter=30):
     """HaplotypeCaller-shaped stream of active regions: region span 50-300 bp plus 100 bp padding
     either side (haplotype length 250-500), 4-32 haplotypes, reads = coverage * span / read_len."""
     rng = np.random.default_rng(seed)
@@ -112,5 +112,5 @@ def make_regions(num_regions, seed=DEFAULT_SEED, coverage=30, read_len=151):
         nr = max(4, int(round(coverage * (span + read_len) / read_len * rng.uniform(0.6, 1.4))))
         haps = make_haplotypes(rng, nh, hap_len, len_jitter=10)
         rl = min(read_len, min(len(h) for h in haps))
-        regions.append(pack(make_reads(rng, haps, nr, rl, len_jitter=30), haps))
+        regions.append(pack(make_reads(rng, haps, nr, rl, len_jitter=read_len_jitter), haps))
     return regions

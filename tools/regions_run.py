@@ -7,7 +7,9 @@ from gatk_amd import synth  # noqa: E402
 from gatk_amd.pairhmm import HipLoglessPairHMM  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-regions = synth.make_regions(n, seed=5)
+jitter = [int(a.split("=")[1]) for a in sys.argv[2:] if a.startswith("jitter=")]  # reads of length 151 - jitter .. 151
+sys.argv = sys.argv[:2] + [a for a in sys.argv[2:] if not a.startswith("jitter=")]
+regions = synth.make_regions(n, seed=5, read_len_jitter=jitter[0] if jitter else 30)
 cells = sum(r.cells for r in regions)
 hmm = HipLoglessPairHMM(0)
 hmm.set_option("timing", 1)
