@@ -544,3 +544,43 @@ def test_random_shapes_and_options(hmm, oracle, seed):
         want = ref(oracle, b)
         assert_parity(g, want)
         assert_parity(g64, want, tol=1e-9)
+
+
+def test_concurrent_handles_one_per_thread(oracle):
+    """The reference makes one PairHMM per map thread (nanoScheduler/NanoScheduler.java:112, pairhmm/PairHMM.java:297):
+    handles used from different threads at the same time must not disturb one another, and a failing call on
+    one thread must leave the other threads' results and error text alone."""
+    import threading
+
+    regions = synth.make_regions(24, seed=77, coverage=8, read_len=100)
+    want = [ref(oracle, b, threads=2) for b in regions]
+    bad = pack([("ACGT", [30] * 4, [45, 45, 200, 45], [45] * 4, [10] * 4)], ["ACGTA"])
+    failures = []
+
+    def work(tid):
+        h = pairhmm.HipLoglessPairHMM(0)
+        try:
+            mine = list(range(tid, len(regions), 4))
+            for rep in range(3):
+                if tid == 0:  # this thread keeps provoking the reference's IllegalArgumentException
+                    try:
+                        h.compute_batch(bad)
+                        failures.append("the bad batch was accepted")
+                    except pairhmm.IllegalArgumentException:
+                        pass
+                got = h.compute_regions([regions[i] for i in mine]) if rep % 2 == 0 else [h.compute_batch(regions[i]) for i in mine]
+                for i, g in zip(mine, got):
+                    fin = np.isfinite(want[i])
+                    if not (np.array_equal(np.isfinite(g), fin) and np.abs(g[fin] - want[i][fin]).max() <= TOL):
+                        failures.append(f"thread {tid} region {i} rep {rep}")
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            failures.append(f"thread {tid}: {e!r}")
+        finally:
+            h.close()
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures, failures
