@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(kWave) sw_fill(const SwArgs A, const int first
     int32_t* const last_col = A.edges + P.edge_off;
     int32_t* const bottom = last_col + (n + 1);
     const int steps = m + (n + K - 1) / K - 1;
+    const int last_row_lane = (n - 1) / K, last_row_r = (n - 1) % K;  // where row n lives
     for (int s = 0; s < steps; ++s) {
         int up = shr1(out_sw), bgv = shr1(out_bgv), gsv = shr1(out_gsv);
         const int j = s - lane + 1;  // 1-based column
@@ -121,7 +122,6 @@ __global__ void __launch_bounds__(kWave) sw_fill(const SwArgs A, const int first
             int diag = diag0;
 #pragma unroll
             for (int r = 0; r < K; ++r) {
-                const int i = row0 + r;
                 const int old_left = left[r];
                 const int step_diag = diag + (a_base[r] == b_base ? A.w_match : A.w_mismatch);
                 // best vertical gap ending here, :283-298
@@ -139,16 +139,25 @@ __global__ void __launch_bounds__(kWave) sw_fill(const SwArgs A, const int first
                 else { val = bgv; btr = gsv; }
                 val = val > kMatrixMinCutoff ? val : kMatrixMinCutoff;
                 bt[(static_cast<int64_t>(s) * K + r) * kWave + lane] = static_cast<int16_t>(btr);  // = btrack_index(i, j, K)
-                if (i <= n) {
-                    if (j == m) last_col[i] = val;
-                    if (i == n) bottom[j] = val;
-                }
                 left[r] = val;
                 diag = old_left;  // sw[i][j-1] is the diagonal of row i + 1
                 up = val;
             }
             diag0 = up_in;
             out_sw = up; out_bgv = bgv; out_gsv = gsv;
+            // the two edges calculateCigar looks at: the last column (once per lane) and the last row
+            // (one row of one lane), kept out of the cell loop so that a cell has no branch
+            if (j == m) {
+#pragma unroll
+                for (int r = 0; r < K; ++r)
+                    if (row0 + r <= n) last_col[row0 + r] = left[r];
+            }
+            if (lane == last_row_lane) {
+                int v = left[0];
+#pragma unroll
+                for (int r = 1; r < K; ++r) v = (r == last_row_r) ? left[r] : v;
+                bottom[j] = v;
+            }
         }
     }
 }
