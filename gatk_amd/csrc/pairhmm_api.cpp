@@ -394,11 +394,13 @@ struct RegionPlan {
     int seg_reads = 0;    // reads in them
 };
 
-int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, const gatk_pairhmm_batch* regions) {
+// checked: the caller has run check_region on these regions already (under their own indices)
+int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, const gatk_pairhmm_batch* regions, bool checked = false) {
     const double t_begin = now_ms();
     if (num_regions < 0 || (num_regions > 0 && !regions)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "regions cannot be null");
-    for (int k = 0; k < num_regions; ++k)
-        if (int rc = check_region(regions[k], k)) return rc;
+    if (!checked)
+        for (int k = 0; k < num_regions; ++k)
+            if (int rc = check_region(regions[k], k)) return rc;
 
     R->num_regions = num_regions;
     R->region_out_off.assign(num_regions + 1, 0);
@@ -1081,6 +1083,39 @@ int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gat
                                  double* const* likelihoods) {
     if (int rc = check_handle(h)) return rc;
     if (num_regions < 0 || (num_regions > 0 && !regions)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "regions cannot be null");
+    for (int k = 0; k < num_regions; ++k)
+        if (int rc = check_region(regions[k], k)) return rc;
+    // A region with more pairs than a part holds is cut by read ranges (its pairs are independent,
+    // PairHMM.java:217): the pieces share its haplotypes and write into consecutive rows of its array.
+    std::vector<gatk_pairhmm_batch> pieces;
+    std::vector<double*> piece_outs;
+    if (h->pipeline_pairs > 0) {
+        bool any_large = false;
+        for (int k = 0; k < num_regions && !any_large; ++k)
+            any_large = regions[k].num_reads > 1 && regions[k].num_haps > 0 &&
+                        static_cast<int64_t>(regions[k].num_reads) * regions[k].num_haps >= 2 * h->pipeline_pairs;
+        if (any_large) {
+            for (int k = 0; k < num_regions; ++k) {
+                const gatk_pairhmm_batch& b = regions[k];
+                const int64_t pairs = b.num_haps > 0 ? static_cast<int64_t>(b.num_reads) * b.num_haps : 0;
+                const int n_pieces = static_cast<int>(std::min<int64_t>(std::max<int64_t>(pairs / h->pipeline_pairs, 1), std::max(b.num_reads, 1)));
+                for (int q = 0; q < n_pieces; ++q) {
+                    const int r0 = static_cast<int>(static_cast<int64_t>(b.num_reads) * q / n_pieces);
+                    const int r1 = static_cast<int>(static_cast<int64_t>(b.num_reads) * (q + 1) / n_pieces);
+                    gatk_pairhmm_batch piece = b;
+                    piece.num_reads = r1 - r0;
+                    if (b.read_offsets) piece.read_offsets = b.read_offsets + r0;  // offsets stay absolute
+                    if (b.read_mapq) piece.read_mapq = b.read_mapq + r0;
+                    pieces.push_back(piece);
+                    double* out = likelihoods ? likelihoods[k] : nullptr;
+                    piece_outs.push_back(out ? out + static_cast<int64_t>(r0) * b.num_haps : nullptr);
+                }
+            }
+            regions = pieces.data();
+            likelihoods = piece_outs.data();
+            num_regions = static_cast<int>(pieces.size());
+        }
+    }
     // parts of about pipeline_pairs pairs, cut between regions; the first two are a quarter and a half of that,
     // so that the device starts early (nothing overlaps the planning of the first part)
     std::vector<int> cuts{0};
@@ -1098,7 +1133,7 @@ int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gat
     }
     cuts.push_back(num_regions);
     if (cuts.size() <= 2) {
-        if (int rc = plan_and_upload(h, &h->scratch, num_regions, regions)) return rc;
+        if (int rc = plan_and_upload(h, &h->scratch, num_regions, regions, true)) return rc;
         if (h->scratch.total_pairs == 0) { h->stats = gatk_pairhmm_stats{}; return GATK_PAIRHMM_OK; }
         if (int rc = enqueue_compute(h, &h->scratch)) return rc;
         return download_into(h, &h->scratch, likelihoods);
@@ -1128,7 +1163,7 @@ int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gat
     int enqueued = 0;
     for (int p = 0; p < parts && rc == GATK_PAIRHMM_OK; ++p) {
         gatk_pairhmm_resident* R = slot[p & 1];
-        rc = plan_and_upload(h, R, cuts[p + 1] - cuts[p], regions + cuts[p]);
+        rc = plan_and_upload(h, R, cuts[p + 1] - cuts[p], regions + cuts[p], true);
         if (rc == GATK_PAIRHMM_OK && R->total_pairs > 0) rc = enqueue_compute(h, R);
         if (rc == GATK_PAIRHMM_OK) enqueued = p + 1;
         if (rc == GATK_PAIRHMM_OK && p >= 1) { rc = fetch(p - 1); fetched = p; }

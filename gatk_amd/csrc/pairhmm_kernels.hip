@@ -257,7 +257,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     unsigned XB[K];
     T P[K], Q[K];
     if constexpr (kScaled) {
-        // expanded once per read by expand_reads: two 16-byte loads per row, no branches, every
+        // expanded once per read by prepare_read: two 16-byte loads per row, no branches, every
         // load of the lane in flight at once
         const int rc_base = ro + 2 * (ld.read_idx >= 0 ? ld.read_idx : 0);
         float4 c0[K], c1[K];

@@ -155,9 +155,10 @@ int gatk_pairhmm_device_count(int32_t* count);
  * instead of using the per-wave emission table), "timing" (1 = fill the *_kernel_ms stats),
  * "stream_mode" (-1 = automatic: a wave scores a run of haplotypes back to back; 0 = one haplotype per
  * work item), "max_stream_haps" (longest run, 1..16), "squash_base_quals" (1 = base qualities under 18 count as 6, see
- * gatk_pairhmm_batch), "pipeline_pairs" (default 131072: a compute_regions call with more
- * pairs is cut between regions into parts of about that many pairs, and one part is planned and copied while
- * the kernels of the part before it run; 0 = never cut), and two knobs for occupancy experiments:
+ * gatk_pairhmm_batch), "pipeline_pairs" (default 131072: a compute call with more
+ * pairs is cut, between regions and inside a large region between reads, into parts of about that many pairs,
+ * and one part is planned and copied while the kernels of the part before it run; 0 = never cut),
+ * "pipeline_ramp" (default 1: the first two parts are a quarter and a half of that), and two knobs for occupancy experiments:
  * "wave_slots" (waves the planner assumes the device holds at once, default 12 per CU) and
  * "stream_lds_floor" (least bytes of LDS a wave of the fp32 stream pass asks for; a larger value
  * lowers the number of waves a CU holds).  Planning options take effect at the next upload or

@@ -500,6 +500,29 @@ def test_error_in_a_later_part_of_an_overlapped_call(hmm):
     assert all(np.isfinite(o).all() for o in hmm.compute_regions(good))
 
 
+def test_one_large_region_is_cut_by_read_ranges(hmm, oracle):
+    """A region with more pairs than a part holds goes through the overlapped path in pieces of consecutive
+    reads (every pair is independent, PairHMM.java:217); zero-length reads and the per-read mapping-quality
+    cap travel with their piece."""
+    b = synth.make_regions(1, seed=41, coverage=40, read_len=120)[0]
+    lens = np.diff(b.read_offsets)
+    # reads 3 and 4 become zero-length: their bytes are dropped from the five arrays
+    keep = np.ones(b.read_offsets[-1], dtype=bool)
+    keep[b.read_offsets[3]:b.read_offsets[5]] = False
+    lens[3] = lens[4] = 0
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    mapq = (20 + np.arange(b.num_reads) % 30).astype(np.uint8)
+    cut = Batch(b.read_bases[keep], b.read_quals[keep], b.ins_gop[keep], b.del_gop[keep], b.gcp[keep], offsets, b.hap_bases, b.hap_offsets, mapq)
+    capped = Batch(cut.read_bases, np.minimum(cut.read_quals, np.repeat(mapq, lens)), cut.ins_gop, cut.del_gop, cut.gcp, offsets, b.hap_bases, b.hap_offsets)
+    want = ref(oracle, capped)
+    for pairs in (0, 7, cut.num_reads * cut.num_haps // 3):
+        got = with_options_pipeline(hmm, pairs, lambda: hmm.compute_batch(cut))
+        assert np.isneginf(got[3:5]).all() and np.isneginf(want[3:5]).all()
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin)
+        assert np.abs(got[fin] - want[fin]).max() <= TOL
+
+
 def with_options_pipeline(hmm, pairs, fn):
     hmm.set_option("pipeline_pairs", pairs)
     try:

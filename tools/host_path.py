@@ -11,6 +11,10 @@ from gatk_amd.pairhmm import HipLoglessPairHMM  # noqa: E402
 b = synth.config_c3()
 hmm = HipLoglessPairHMM(0)
 hmm.set_option("timing", 1)
+for kv in sys.argv[1:]:  # engine options as name=value
+    name, value = kv.split("=")
+    hmm.set_option(name, float(value))
+hmm.compute_batch(b)
 hmm.compute_batch(b)
 best = 1e9
 for _ in range(8):
@@ -18,6 +22,6 @@ for _ in range(8):
     hmm.compute_batch(b)
     best = min(best, time.perf_counter() - t0)
 st = hmm.stats()
-print(f"C3 host-pointer call: {1e3 * best:.2f} ms wall ({b.cells / best / 1e9:.0f} GCUPS); plan {st['host_plan_ms']:.2f} ms, upload {st['host_upload_ms']:.2f} ms, "
+print(f"{' '.join(sys.argv[1:]) or 'defaults'}: C3 host-pointer call: {1e3 * best:.2f} ms wall ({b.cells / best / 1e9:.0f} GCUPS); plan {st['host_plan_ms']:.2f} ms, upload {st['host_upload_ms']:.2f} ms, "
       f"kernels {st['fp32_kernel_ms'] + st['fp64_kernel_ms'] + st['aux_kernel_ms']:.2f} ms")
 hmm.close()
