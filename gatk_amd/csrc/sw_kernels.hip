@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <climits>
 #include <cstdint>
 #include <cstdlib>
@@ -33,6 +34,8 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kMaxRowsPerLane = 32;
 constexpr int kMaxRef = kWave * kMaxRowsPerLane;  // 2048
+constexpr int kNumRowChoices = 13;
+constexpr int kRowChoices[kNumRowChoices] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 24, 32};  // rows per lane a fill kernel exists for
 constexpr int kMaxAlt = 16000;
 constexpr int kLowInit = INT_MIN / 2;             // lowInitValue, :235
 constexpr int kMatrixMinCutoff = -100000000;      // (int) -1e8, :233 (the static cutoff flag is false)
@@ -59,6 +62,7 @@ struct SwArgs {
     int32_t* edges;
     int32_t* elems;
     PairResult* results;
+    const int32_t* order;  // pair indices grouped by rows per lane: a launch takes a contiguous range of it
     int32_t num_pairs;
     int32_t w_match, w_mismatch, w_open, w_extend;
     int32_t strategy;
@@ -82,9 +86,7 @@ __device__ __forceinline__ int edge_score(const SwArgs& A, int k) {
 template <int K>
 __global__ void __launch_bounds__(kWave) sw_fill(const SwArgs A, const int first_pair) {
     extern __shared__ uint8_t alt_lds[];  // [64 pad][alternate][64 pad]
-    const int pair_idx = first_pair + blockIdx.x;
-    if (pair_idx >= A.num_pairs) return;
-    const PairDesc P = A.pairs[pair_idx];
+    const PairDesc P = A.pairs[A.order[first_pair + blockIdx.x]];  // the grid is exactly this launch's range
     const int lane = threadIdx.x;
     const int n = P.n, m = P.m;
     const uint8_t* ref = A.pool + P.ref_off;
@@ -163,9 +165,10 @@ __global__ void __launch_bounds__(kWave) sw_fill(const SwArgs A, const int first
 }
 
 // calculateCigar, :350-470, one thread per pair: the raw element list (last element first) and the offset.
-__global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= A.num_pairs) return;
+__global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A, const int first_pair, const int num) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= num) return;
+    const int k = A.order[first_pair + x];
     const PairDesc P = A.pairs[k];
     const int refLength = P.n, altLength = P.m;
     const int16_t* bt = A.btrack + P.btrack_off;
@@ -240,19 +243,37 @@ int fail(int code, const std::string& msg) {
         if (e_ != hipSuccess) return fail(GATK_SW_DEVICE_ERROR, std::string(#expr ": ") + hipGetErrorString(e_)); \
     } while (0)
 
-// Grow-only device scratch of the calling thread (one per device it has used).
+constexpr int kSideStreams = 3;
+
+// Grow-only device scratch of the calling thread (one per device it has used), and its streams: the fill
+// launches of a call (one per rows-per-lane value) are short on waves each, so they run side by side.
 struct Scratch {
     int device = -1;
     void* p = nullptr;
     size_t cap = 0;
+    hipStream_t main = nullptr, side[kSideStreams] = {};
+    hipEvent_t fork = nullptr, join[kSideStreams] = {};
 };
 thread_local std::vector<Scratch> g_scratch;
 
-hipError_t scratch_for(int device, size_t bytes, void** out) {
+hipError_t scratch_for(int device, size_t bytes, void** out, Scratch** scratch) {
     Scratch* s = nullptr;
     for (auto& x : g_scratch)
         if (x.device == device) s = &x;
-    if (!s) { g_scratch.push_back(Scratch{device, nullptr, 0}); s = &g_scratch.back(); }
+    if (!s) {
+        Scratch fresh;
+        fresh.device = device;
+        hipError_t e = hipStreamCreateWithFlags(&fresh.main, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&fresh.fork, hipEventDisableTiming);
+        for (int k = 0; k < kSideStreams && e == hipSuccess; ++k) {
+            e = hipStreamCreateWithFlags(&fresh.side[k], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&fresh.join[k], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) return e;
+        g_scratch.push_back(fresh);
+        s = &g_scratch.back();
+    }
+    *scratch = s;
     if (bytes > s->cap) {
         if (s->p) { hipError_t e = hipFree(s->p); s->p = nullptr; s->cap = 0; if (e != hipSuccess) return e; }
         const size_t want = bytes + bytes / 4 + 4096;
@@ -267,8 +288,8 @@ hipError_t scratch_for(int device, size_t bytes, void** out) {
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 template <int K>
-hipError_t launch_fill(const SwArgs& A, int num_pairs, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL((sw_fill<K>), dim3(num_pairs), dim3(kWave), lds, stream, A, 0);
+hipError_t launch_fill(const SwArgs& A, int first, int count, size_t lds, hipStream_t stream) {
+    hipLaunchKernelGGL((sw_fill<K>), dim3(count), dim3(kWave), lds, stream, A, first);
     return hipGetLastError();
 }
 
@@ -297,7 +318,7 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
     // ---- layout -----------------------------------------------------------------------------------
     std::vector<PairDesc> pairs(num_pairs);
     size_t pool_bytes = 0, bt_entries = 0, edge_ints = 0, elem_ints = 0;
-    int max_n = 0, max_m = 0;
+    int max_m = 0;
     for (int k = 0; k < num_pairs; ++k) {
         const int n = reference_lengths[k], m = alternate_lengths[k];
         if (!references[k] || n <= 0 || !alternates[k] || m <= 0)  // SWPairwiseAlignment.java:183-184
@@ -309,7 +330,6 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
         P.n = n; P.m = m;
         P.ref_off = static_cast<int64_t>(pool_bytes); pool_bytes += align_up(n, 16);
         P.alt_off = static_cast<int64_t>(pool_bytes); pool_bytes += align_up(m, 16);
-        max_n = std::max(max_n, n);
         P.edge_off = static_cast<int64_t>(edge_ints); edge_ints += static_cast<size_t>(n + 1) + (m + 1);
         // an element is added when the back-track changes state, plus a few at the ends: a list that outgrows
         // this cannot consolidate into cigar_capacity elements
@@ -317,18 +337,32 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
         P.elem_off = static_cast<int64_t>(elem_ints); elem_ints += 2 * static_cast<size_t>(P.elem_cap);
         max_m = std::max(max_m, m);
     }
-    // rows per lane: the smallest instantiation that holds the longest reference of the call
-    const int need = (max_n + kWave - 1) / kWave;
-    const int K = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 16 ? 16 : 32;
-    for (PairDesc& P : pairs) {
-        const size_t steps = static_cast<size_t>(P.m) + (P.n + K - 1) / K - 1;
-        P.rows_per_lane = K;
-        P.btrack_off = static_cast<int64_t>(bt_entries);
-        bt_entries += steps * K * kWave;
+    // rows per lane: per pair, the smallest instantiation that holds its reference; one launch per value
+    std::vector<int32_t> order(num_pairs);
+    std::array<int, kNumRowChoices + 1> group_begin{};
+    {
+        std::array<int, kNumRowChoices> count{};
+        std::vector<uint8_t> choice(num_pairs);
+        for (int k = 0; k < num_pairs; ++k) {
+            PairDesc& P = pairs[k];
+            const int need = (P.n + kWave - 1) / kWave;
+            int c = 0;
+            while (kRowChoices[c] < need) ++c;
+            const int K = kRowChoices[c];
+            choice[k] = static_cast<uint8_t>(c);
+            ++count[c];
+            const size_t steps = static_cast<size_t>(P.m) + (P.n + K - 1) / K - 1;
+            P.rows_per_lane = K;
+            P.btrack_off = static_cast<int64_t>(bt_entries);
+            bt_entries += steps * K * kWave;
+        }
+        for (int c = 0; c < kNumRowChoices; ++c) group_begin[c + 1] = group_begin[c] + count[c];
+        std::array<int, kNumRowChoices> at{};
+        for (int k = 0; k < num_pairs; ++k) order[group_begin[choice[k]] + at[choice[k]]++] = k;
     }
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t at = off; off = align_up(off + bytes, 256); return at; };
-    const size_t o_pool = carve(pool_bytes), o_pairs = carve(pairs.size() * sizeof(PairDesc));
+    const size_t o_pool = carve(pool_bytes), o_pairs = carve(pairs.size() * sizeof(PairDesc)), o_order = carve(order.size() * sizeof(int32_t));
     const size_t upload_bytes = off;
     const size_t o_bt = carve(bt_entries * sizeof(int16_t)), o_edges = carve(edge_ints * sizeof(int32_t)),
                  o_elems = carve(elem_ints * sizeof(int32_t)), o_results = carve(pairs.size() * sizeof(PairResult));
@@ -338,13 +372,15 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
         memcpy(host.data() + o_pool + pairs[k].alt_off, alternates[k], pairs[k].m);
     }
     memcpy(host.data() + o_pairs, pairs.data(), pairs.size() * sizeof(PairDesc));
+    memcpy(host.data() + o_order, order.data(), order.size() * sizeof(int32_t));
 
     // ---- device -----------------------------------------------------------------------------------
     SW_TRY(hipSetDevice(device));
     void* base = nullptr;
-    SW_TRY(scratch_for(device, off, &base));
+    Scratch* sc = nullptr;
+    SW_TRY(scratch_for(device, off, &base, &sc));
     uint8_t* D = static_cast<uint8_t*>(base);
-    hipStream_t stream = nullptr;  // the null stream: calls of one thread are ordered, results are fetched synchronously
+    hipStream_t stream = sc->main;  // this thread's stream on the device: its calls are ordered, results are fetched synchronously
     SW_TRY(hipMemcpyAsync(D, host.data(), upload_bytes, hipMemcpyHostToDevice, stream));
     SwArgs A{};
     A.pool = D + o_pool;
@@ -353,19 +389,50 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
     A.edges = reinterpret_cast<int32_t*>(D + o_edges);
     A.elems = reinterpret_cast<int32_t*>(D + o_elems);
     A.results = reinterpret_cast<PairResult*>(D + o_results);
+    A.order = reinterpret_cast<const int32_t*>(D + o_order);
     A.num_pairs = num_pairs;
     A.w_match = parameters->w_match; A.w_mismatch = parameters->w_mismatch; A.w_open = parameters->w_open; A.w_extend = parameters->w_extend;
     A.strategy = overhang_strategy;
     const size_t lds = static_cast<size_t>(max_m) + 2 * kWave;
-    hipError_t e;
-    if (K == 1) e = launch_fill<1>(A, num_pairs, lds, stream);
-    else if (K == 2) e = launch_fill<2>(A, num_pairs, lds, stream);
-    else if (K == 4) e = launch_fill<4>(A, num_pairs, lds, stream);
-    else if (K == 8) e = launch_fill<8>(A, num_pairs, lds, stream);
-    else if (K == 16) e = launch_fill<16>(A, num_pairs, lds, stream);
-    else e = launch_fill<32>(A, num_pairs, lds, stream);
-    SW_TRY(e);
-    hipLaunchKernelGGL(sw_backtrack, dim3((num_pairs + 63) / 64), dim3(64), 0, stream, A);
+    SW_TRY(hipEventRecord(sc->fork, stream));
+    int launches = 0;
+    bool side_used[kSideStreams] = {};
+    for (int c = kNumRowChoices - 1; c >= 0; --c) {  // most rows per lane first: those waves run longest
+        const int first = group_begin[c], count = group_begin[c + 1] - first;
+        if (count == 0) continue;
+        hipStream_t stream = sc->main;  // the first launch stays on the main stream, the others fan out
+        if (launches > 0) {
+            const int k = (launches - 1) % kSideStreams;
+            stream = sc->side[k];
+            if (!side_used[k]) SW_TRY(hipStreamWaitEvent(stream, sc->fork, 0));
+            side_used[k] = true;
+        }
+        ++launches;
+        hipError_t e = hipErrorInvalidValue;
+        switch (kRowChoices[c]) {
+            case 1: e = launch_fill<1>(A, first, count, lds, stream); break;
+            case 2: e = launch_fill<2>(A, first, count, lds, stream); break;
+            case 3: e = launch_fill<3>(A, first, count, lds, stream); break;
+            case 4: e = launch_fill<4>(A, first, count, lds, stream); break;
+            case 5: e = launch_fill<5>(A, first, count, lds, stream); break;
+            case 6: e = launch_fill<6>(A, first, count, lds, stream); break;
+            case 7: e = launch_fill<7>(A, first, count, lds, stream); break;
+            case 8: e = launch_fill<8>(A, first, count, lds, stream); break;
+            case 10: e = launch_fill<10>(A, first, count, lds, stream); break;
+            case 12: e = launch_fill<12>(A, first, count, lds, stream); break;
+            case 16: e = launch_fill<16>(A, first, count, lds, stream); break;
+            case 24: e = launch_fill<24>(A, first, count, lds, stream); break;
+            case 32: e = launch_fill<32>(A, first, count, lds, stream); break;
+        }
+        SW_TRY(e);
+    }
+    for (int k = 0; k < kSideStreams; ++k) {
+        if (!side_used[k]) continue;
+        SW_TRY(hipEventRecord(sc->join[k], sc->side[k]));
+        SW_TRY(hipStreamWaitEvent(stream, sc->join[k], 0));
+    }
+    // one back-track launch behind all fills (run next to them it slows them more than it gains)
+    hipLaunchKernelGGL(sw_backtrack, dim3((num_pairs + 63) / 64), dim3(64), 0, stream, A, 0, num_pairs);
     SW_TRY(hipGetLastError());
     std::vector<PairResult> results(num_pairs);
     std::vector<int32_t> elems(elem_ints);

@@ -54,13 +54,30 @@ def test_random_haplotype_like_pairs(oracle, parameters, strategy):
         assert (cigar, off) == (want_cigar, want_off), (r, a)
 
 
-@pytest.mark.parametrize("ref_len", [1, 2, 63, 64, 65, 128, 129, 500, 1025, 2048])
+# one length per fill-kernel instantiation (rows per lane 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 24, 32) and the edges between them
+@pytest.mark.parametrize("ref_len", [1, 2, 63, 64, 65, 128, 129, 192, 193, 300, 380, 440, 500, 600, 700, 1000, 1025, 1536, 1537, 2048])
 def test_every_rows_per_lane_instantiation(oracle, ref_len):
     rng = np.random.default_rng(ref_len)
     refs, alts = random_pairs(rng, 6, ref_len, 0)
     alts[0] = b"A"                       # one-base alternate
     alts[1] = refs[1]                    # identical
     for strategy in (sw.SOFTCLIP, sw.INDEL):
+        got = sw.align_batch(refs, alts, sw.STANDARD_NGS, strategy)
+        for r, a, g in zip(refs, alts, got):
+            rc, c, o = oracle.sw_align(r, a, sw.STANDARD_NGS, strategy)
+            assert rc == 0 and g == (c, o)
+
+
+def test_one_call_with_references_of_many_lengths(oracle):
+    """Every pair takes the fill kernel that fits its own reference: one call, several launches, results in
+    the caller's order."""
+    rng = np.random.default_rng(12)
+    refs, alts = [], []
+    for ref_len in (40, 700, 130, 260, 2000, 64, 450, 330, 1100, 90, 520, 400):
+        r, a = random_pairs(rng, 3, ref_len, 10)
+        refs += r
+        alts += a
+    for strategy in (sw.SOFTCLIP, sw.LEADING_INDEL):
         got = sw.align_batch(refs, alts, sw.STANDARD_NGS, strategy)
         for r, a, g in zip(refs, alts, got):
             rc, c, o = oracle.sw_align(r, a, sw.STANDARD_NGS, strategy)
