@@ -4,6 +4,7 @@ getAlignmentStart2wrt1(); constructors smithwaterman/SWPairwiseAlignment.java:13
 
 The GPU does the work; without one the calls raise (there is no CPU path)."""
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -20,6 +21,9 @@ _OPS = "MIDS"
 
 class CParameters(C.Structure):
     _fields_ = [("w_match", C.c_int32), ("w_mismatch", C.c_int32), ("w_open", C.c_int32), ("w_extend", C.c_int32)]
+
+
+last_call_seconds = 0.0  # wall time of the last gatk_sw_align call, without this module's marshalling
 
 
 class CigarTooLong(RuntimeError):
@@ -52,9 +56,12 @@ def align_batch(references, alternates, parameters=ORIGINAL_DEFAULT, strategy=SO
     offsets = np.zeros(n, dtype=np.int32)
     par = CParameters(*[int(x) for x in parameters])
     L = _lib()
+    global last_call_seconds
+    t0 = time.perf_counter()
     rc = L.gatk_sw_align(C.c_int32(device), C.c_int32(n), rp, C.c_void_p(rl.ctypes.data), ap, C.c_void_p(al.ctypes.data), C.byref(par),
                          C.c_int32(strategy), C.c_int32(cigar_capacity), C.c_void_p(ops.ctypes.data), C.c_void_p(lens.ctypes.data),
                          C.c_void_p(counts.ctypes.data), C.c_void_p(offsets.ctypes.data))
+    last_call_seconds = time.perf_counter() - t0
     if rc != 0:
         msg = L.gatk_sw_last_error().decode()
         raise {1: IllegalArgumentException, 5: CigarTooLong}.get(rc, DeviceError)(msg)

@@ -25,16 +25,17 @@ for _ in range(pairs):
     alts.append(alt.tobytes())
 cells = sum(len(r) * len(a) for r, a in zip(refs, alts))
 sw.align_batch(refs[:8], alts[:8], sw.STANDARD_NGS, sw.SOFTCLIP)
-best = 1e9
+best = best_c = 1e9
 for _ in range(3):
     t0 = time.perf_counter()
     got = sw.align_batch(refs, alts, sw.STANDARD_NGS, sw.SOFTCLIP)
     best = min(best, time.perf_counter() - t0)
+    best_c = min(best_c, sw.last_call_seconds)
 sample = min(pairs, 200)
 t0 = time.perf_counter()
 want = [O.sw_align(r, a, O.SW_STANDARD_NGS, O.SW_SOFTCLIP)[1:] for r, a in zip(refs[:sample], alts[:sample])]
 cpu = time.perf_counter() - t0
 assert got[:sample] == want
 cpu_cells = sum(len(r) * len(a) for r, a in zip(refs[:sample], alts[:sample]))
-print(f"{pairs} alignments, {cells:.3e} cells: GPU {1e3 * best:.2f} ms wall incl. copies ({cells / best / 1e9:.1f} GCUPS); "
+print(f"{pairs} alignments, {cells:.3e} cells: GPU {1e3 * best_c:.2f} ms in gatk_sw_align incl. copies ({cells / best_c / 1e9:.1f} GCUPS), {1e3 * best:.2f} ms with the Python marshalling; "
       f"scalar CPU oracle {cpu_cells / cpu / 1e9:.3f} GCUPS on one thread ({sample} alignments)")
