@@ -34,6 +34,7 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kMaxRowsPerLane = 32;
 constexpr int kMaxRef = kWave * kMaxRowsPerLane;  // 2048
+constexpr int kHeadElems = 16;  // raw CIGAR elements of a pair that come back with the first copy
 constexpr int kNumRowChoices = 13;
 constexpr int kRowChoices[kNumRowChoices] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 24, 32};  // rows per lane a fill kernel exists for
 constexpr int kMaxAlt = 16000;
@@ -61,6 +62,7 @@ struct SwArgs {
     int16_t* btrack;
     int32_t* edges;
     int32_t* elems;
+    int32_t* heads;        // [num_pairs][kHeadElems][2]: the first raw elements of every pair again, packed for one copy
     PairResult* results;
     const int32_t* order;  // pair indices grouped by rows per lane: a launch takes a contiguous range of it
     int32_t num_pairs;
@@ -175,9 +177,11 @@ __global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A, const int fir
     const int32_t* last_col = A.edges + P.edge_off;
     const int32_t* bottom = last_col + (refLength + 1);
     int32_t* elems = A.elems + P.elem_off;
+    int32_t* heads = A.heads + static_cast<int64_t>(k) * 2 * kHeadElems;
     int count = 0;
     auto add = [&](int op, int len) {
         if (count < P.elem_cap) { elems[2 * count] = op; elems[2 * count + 1] = len; }
+        if (count < kHeadElems) { heads[2 * count] = op; heads[2 * count + 1] = len; }
         ++count;
     };
     int p1 = 0, p2 = 0, maxscore = INT_MIN, segment_length = 0;
@@ -318,6 +322,7 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
     // ---- layout -----------------------------------------------------------------------------------
     std::vector<PairDesc> pairs(num_pairs);
     size_t pool_bytes = 0, bt_entries = 0, edge_ints = 0, elem_ints = 0;
+    const int elem_stride = 2 * cigar_capacity + 16;  // raw elements kept per pair
     int max_m = 0;
     for (int k = 0; k < num_pairs; ++k) {
         const int n = reference_lengths[k], m = alternate_lengths[k];
@@ -333,8 +338,8 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
         P.edge_off = static_cast<int64_t>(edge_ints); edge_ints += static_cast<size_t>(n + 1) + (m + 1);
         // an element is added when the back-track changes state, plus a few at the ends: a list that outgrows
         // this cannot consolidate into cigar_capacity elements
-        P.elem_cap = std::min(n + m + 8, 2 * cigar_capacity + 16);
-        P.elem_off = static_cast<int64_t>(elem_ints); elem_ints += 2 * static_cast<size_t>(P.elem_cap);
+        P.elem_cap = std::min(n + m + 8, elem_stride);
+        P.elem_off = static_cast<int64_t>(elem_ints); elem_ints += 2 * static_cast<size_t>(elem_stride);  // every pair the same stride: see the fetch
         max_m = std::max(max_m, m);
     }
     // rows per lane: per pair, the smallest instantiation that holds its reference; one launch per value
@@ -365,7 +370,8 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
     const size_t o_pool = carve(pool_bytes), o_pairs = carve(pairs.size() * sizeof(PairDesc)), o_order = carve(order.size() * sizeof(int32_t));
     const size_t upload_bytes = off;
     const size_t o_bt = carve(bt_entries * sizeof(int16_t)), o_edges = carve(edge_ints * sizeof(int32_t)),
-                 o_elems = carve(elem_ints * sizeof(int32_t)), o_results = carve(pairs.size() * sizeof(PairResult));
+                 o_elems = carve(elem_ints * sizeof(int32_t)), o_results = carve(pairs.size() * sizeof(PairResult)),
+                 o_heads = carve(pairs.size() * 2 * kHeadElems * sizeof(int32_t));
     std::vector<uint8_t> host(upload_bytes, 0);
     for (int k = 0; k < num_pairs; ++k) {
         memcpy(host.data() + o_pool + pairs[k].ref_off, references[k], pairs[k].n);
@@ -388,6 +394,7 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
     A.btrack = reinterpret_cast<int16_t*>(D + o_bt);
     A.edges = reinterpret_cast<int32_t*>(D + o_edges);
     A.elems = reinterpret_cast<int32_t*>(D + o_elems);
+    A.heads = reinterpret_cast<int32_t*>(D + o_heads);
     A.results = reinterpret_cast<PairResult*>(D + o_results);
     A.order = reinterpret_cast<const int32_t*>(D + o_order);
     A.num_pairs = num_pairs;
@@ -435,15 +442,38 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
     hipLaunchKernelGGL(sw_backtrack, dim3((num_pairs + 63) / 64), dim3(64), 0, stream, A, 0, num_pairs);
     SW_TRY(hipGetLastError());
     std::vector<PairResult> results(num_pairs);
-    std::vector<int32_t> elems(elem_ints);
+    // Raw element lists: alignments of haplotypes have a handful of elements, so the first kHeadElems of every
+    // pair come back packed in one copy and the rest of the few longer lists afterwards.
+    const int head = std::min(kHeadElems, elem_stride);
+    std::vector<int32_t> heads(static_cast<size_t>(num_pairs) * 2 * kHeadElems);
     SW_TRY(hipMemcpyAsync(results.data(), D + o_results, results.size() * sizeof(PairResult), hipMemcpyDeviceToHost, stream));
-    SW_TRY(hipMemcpyAsync(elems.data(), D + o_elems, elems.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    SW_TRY(hipMemcpyAsync(heads.data(), D + o_heads, heads.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     SW_TRY(hipStreamSynchronize(stream));
+    std::vector<int32_t> tails;                          // elements head.. of the pairs that have them, back to back
+    std::vector<int64_t> tail_at(num_pairs, -1);         // a pair's offset in tails
+    {
+        size_t tail_ints = 0;
+        for (int k = 0; k < num_pairs; ++k) {
+            const int have = std::min(results[k].num_elems, pairs[k].elem_cap);
+            if (have > head) { tail_at[k] = static_cast<int64_t>(tail_ints); tail_ints += 2 * static_cast<size_t>(have - head); }
+        }
+        if (tail_ints > 0) {
+            tails.resize(tail_ints);
+            for (int k = 0; k < num_pairs; ++k) {
+                if (tail_at[k] < 0) continue;
+                const int have = std::min(results[k].num_elems, pairs[k].elem_cap);
+                const size_t src = (static_cast<size_t>(pairs[k].elem_off) + 2 * static_cast<size_t>(head)) * sizeof(int32_t);
+                SW_TRY(hipMemcpyAsync(tails.data() + tail_at[k], D + o_elems + src, static_cast<size_t>(have - head) * 8, hipMemcpyDeviceToHost, stream));
+            }
+            SW_TRY(hipStreamSynchronize(stream));
+        }
+    }
 
     // ---- Collections.reverse + AlignmentUtils.consolidateCigar (sam/AlignmentUtils.java:698-727) -------
     int rc = GATK_SW_OK;
     for (int k = 0; k < num_pairs; ++k) {
-        const int32_t* raw = elems.data() + pairs[k].elem_off;
+        const int32_t* raw_head = heads.data() + static_cast<size_t>(k) * 2 * kHeadElems;
+        const int32_t* raw_tail = tail_at[k] >= 0 ? tails.data() + tail_at[k] : nullptr;
         if (results[k].num_elems > pairs[k].elem_cap)
             rc = fail(GATK_SW_CIGAR_TOO_LONG, "pair " + std::to_string(k) + " needs more than cigar_capacity elements");
         const int count = std::min(results[k].num_elems, pairs[k].elem_cap);
@@ -456,7 +486,8 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
             ++out;
         };
         for (int x = count - 1; x >= 0; --x) {
-            const int op = raw[2 * x], len = raw[2 * x + 1];
+            const int32_t* e = x < head ? raw_head + 2 * x : raw_tail + 2 * (x - head);
+            const int op = e[0], len = e[1];
             if (len == 0) continue;
             if (last != -1 && last != op) { emit(last, sum); sum = 0; }
             sum += len;

@@ -84,6 +84,27 @@ def test_one_call_with_references_of_many_lengths(oracle):
             assert rc == 0 and g == (c, o)
 
 
+def test_alignments_with_many_cigar_elements(oracle):
+    """Lists longer than what the first fetch of a call brings back (many indels), next to short ones."""
+    rng = np.random.default_rng(3)
+    refs, alts = [], []
+    for n_indels in (0, 14, 2, 20):
+        ref = "".join(rng.choice(list("ACGT"), size=900))
+        alt, at = [], 0
+        for k in range(n_indels):
+            nxt = at + 900 // (n_indels + 1)
+            alt.append(ref[at:nxt - 6] if k % 2 == 0 else ref[at:nxt] + "TTTTT")  # a deletion or an insertion
+            at = nxt
+        alt.append(ref[at:])
+        refs.append(ref.encode())
+        alts.append("".join(alt).encode())
+    got = sw.align_batch(refs, alts, sw.STANDARD_NGS, sw.SOFTCLIP)
+    assert max(c.count("D") + c.count("I") for c, _ in got) >= 14
+    for r, a, g in zip(refs, alts, got):
+        rc, c, o = oracle.sw_align(r, a, sw.STANDARD_NGS, sw.SOFTCLIP)
+        assert rc == 0 and g == (c, o)
+
+
 def test_the_reference_benchmark_sequences(oracle):
     # smithwaterman/SmithWatermanBenchmark.java:48-72: two SNPs ('X' against 'Y') in runs of 'A'
     refs, alts = [], []
