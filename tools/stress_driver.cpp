@@ -62,7 +62,8 @@ Region make_region(Rng& g, bool allow_empty) {
     }
     const int nr = allow_empty && g.range(0, 15) == 0 ? 0 : g.range(1, 90);
     for (int k = 0; k < nr; ++k) {
-        const int len = g.range(0, 30) == 0 ? 0 : g.range(1, std::min(span, g.range(0, 5) == 0 ? 260 : 151));
+        // a region whose reads are all empty is the reference's "READ_MAX_LENGTH must be > 0": keep read 0 non-empty
+        const int len = (k > 0 && g.range(0, 30) == 0) ? 0 : g.range(1, std::min(span, g.range(0, 5) == 0 ? 260 : 151));
         const int start = g.range(0, span - std::max(len, 1));
         const bool noisy = g.range(0, 25) == 0;  // many errors at high quality: the fp32 sum underflows
         for (int i = 0; i < len; ++i) {
