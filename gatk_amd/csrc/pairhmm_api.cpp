@@ -13,6 +13,10 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -179,6 +183,7 @@ struct gatk_pairhmm {
     int device = 0;
     hipStream_t stream = nullptr;
     int wave_slots = 3072;  // waves the device holds at once at three per SIMD
+    bool combine_calls = false;  // small compute_likelihoods calls of all threads on this device share device passes
     bool pipeline_ramp = true;  // the first two parts of a cut call are a quarter and a half of pipeline_pairs
     int stream_lds_floor = 0;  // least LDS bytes per wave of the stream pass (caps the waves a CU holds)
     double* d_err = nullptr;
@@ -1184,6 +1189,97 @@ int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gat
     return GATK_PAIRHMM_OK;
 }
 
+namespace {
+
+// Region-sized calls from several threads, each on its own handle (the reference's one PairHMM per map
+// thread, PairHMM.java:297), do not fill the device one at a time and do not overlap well either.  With the
+// handle option "combine_calls" such calls meet here: whichever caller finds an engine free takes every
+// request that is waiting on the device, its own included, through one gatk_pairhmm_compute_regions pass on
+// that engine and hands the results out; callers that arrive meanwhile wait for the next pass.  Two engines
+// per device, so that one pass is planned while another runs.  They live until the process ends.
+struct Combiner {
+    struct Request {
+        const gatk_pairhmm_batch* batch;
+        double* out;
+        int rc = GATK_PAIRHMM_OK;
+        std::string error;
+        bool taken = false, done = false;
+    };
+    static constexpr int kEngines = 2;
+    static constexpr size_t kMaxRequestsPerPass = 64;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Request*> pending;
+    gatk_pairhmm* engine[kEngines] = {};
+    bool busy[kEngines] = {};
+};
+
+std::mutex g_combiners_mutex;
+std::map<int, Combiner*> g_combiners;
+
+// One combiner per device and per value of the one result-changing option it supports (squash_base_quals).
+Combiner* combiner_for(int device, bool squash) {
+    std::lock_guard<std::mutex> lock(g_combiners_mutex);
+    Combiner*& c = g_combiners[device * 2 + (squash ? 1 : 0)];
+    if (!c) c = new Combiner();
+    return c;
+}
+
+// One pass over the requests a leader took.  A failing pass is repeated request by request so that the
+// reference's exception reaches the caller whose batch raised it, and only that caller.
+void run_combined(gatk_pairhmm* engine, const std::vector<Combiner::Request*>& reqs) {
+    std::vector<gatk_pairhmm_batch> batches;
+    std::vector<double*> outs;
+    for (const Combiner::Request* r : reqs) { batches.push_back(*r->batch); outs.push_back(r->out); }
+    if (gatk_pairhmm_compute_regions(engine, static_cast<int32_t>(reqs.size()), batches.data(), outs.data()) == GATK_PAIRHMM_OK) return;
+    for (size_t k = 0; k < reqs.size(); ++k) {
+        reqs[k]->rc = gatk_pairhmm_compute_regions(engine, 1, &batches[k], &outs[k]);
+        if (reqs[k]->rc != GATK_PAIRHMM_OK) reqs[k]->error = g_last_error;
+    }
+}
+
+int compute_combined(int device, bool squash, const gatk_pairhmm_batch* batch, double* out) {
+    Combiner* c = combiner_for(device, squash);
+    Combiner::Request mine{batch, out};
+    std::unique_lock<std::mutex> lock(c->m);
+    c->pending.push_back(&mine);
+    while (!mine.done) {
+        int e = -1;
+        if (!mine.taken)
+            for (int k = 0; k < Combiner::kEngines && e < 0; ++k)
+                if (!c->busy[k]) e = k;
+        if (e < 0) { c->cv.wait(lock); continue; }
+        // lead a pass on engine e
+        c->busy[e] = true;
+        std::vector<Combiner::Request*> reqs;
+        while (!c->pending.empty() && reqs.size() < Combiner::kMaxRequestsPerPass) {
+            reqs.push_back(c->pending.front());
+            c->pending.pop_front();
+            reqs.back()->taken = true;
+        }
+        int create_rc = GATK_PAIRHMM_OK;
+        std::string create_error;
+        lock.unlock();
+        if (!c->engine[e]) {  // only the thread that holds busy[e] touches engine[e]
+            create_rc = gatk_pairhmm_create(device, &c->engine[e]);
+            if (create_rc == GATK_PAIRHMM_OK) c->engine[e]->squash_base_quals = squash;
+            else create_error = g_last_error;
+        }
+        if (create_rc == GATK_PAIRHMM_OK) run_combined(c->engine[e], reqs);
+        lock.lock();
+        for (Combiner::Request* r : reqs) {
+            if (create_rc != GATK_PAIRHMM_OK) { r->rc = create_rc; r->error = create_error; }
+            r->done = true;
+        }
+        c->busy[e] = false;
+        c->cv.notify_all();
+    }
+    lock.unlock();
+    return mine.rc == GATK_PAIRHMM_OK ? GATK_PAIRHMM_OK : fail(mine.rc, mine.error);
+}
+
+}  // namespace
+
 int gatk_pairhmm_compute_likelihoods(gatk_pairhmm* h, const gatk_pairhmm_batch* batch, double* likelihoods) {
     if (int rc = check_handle(h)) return rc;
     if (!batch) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "batch cannot be null");
@@ -1191,7 +1287,22 @@ int gatk_pairhmm_compute_likelihoods(gatk_pairhmm* h, const gatk_pairhmm_batch* 
     const int64_t n = static_cast<int64_t>(batch->num_reads) * std::max(batch->num_haps, 0);
     if (n > 0 && !likelihoods) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "likelihoods cannot be null");
     double* outs[1] = {likelihoods};
-    if (int rc = gatk_pairhmm_compute_regions(h, 1, batch, outs)) return rc;
+    // combined: a call that cannot fill the device by itself, on a handle whose other options are the defaults
+    const bool plain = h->fp32_threshold == 1e-28f && h->force_rows_per_lane == 0 && !h->force_fp64 && h->emit_mode == -1 &&
+                       h->stream_mode == -1 && !h->timing;
+    if (h->combine_calls && plain && n < 4 * static_cast<int64_t>(h->wave_slots)) {
+        if (int rc = check_region(*batch, 0)) return rc;
+        if (int rc = compute_combined(h->device, h->squash_base_quals, batch, likelihoods)) return rc;
+        h->stats = gatk_pairhmm_stats{};
+        h->stats.pairs = n;
+        // PairHMM.java:200-201: this instance's maxima grow with the batches it has seen
+        int read_max = 0, hap_max = 0;
+        for (int r = 0; r < batch->num_reads; ++r) read_max = std::max(read_max, batch->read_offsets[r + 1] - batch->read_offsets[r]);
+        for (int a = 0; a < batch->num_haps; ++a) hap_max = std::max(hap_max, batch->hap_offsets[a + 1] - batch->hap_offsets[a]);
+        h->max_read = std::max(h->max_read, read_max);
+        h->max_hap = std::max(h->max_hap, hap_max);
+        h->initialized = true;
+    } else if (int rc = gatk_pairhmm_compute_regions(h, 1, batch, outs)) return rc;
     h->likelihood_array.assign(likelihoods, likelihoods + n);  // mLikelihoodArray, PairHMM.java:206,225
     return GATK_PAIRHMM_OK;
 }
@@ -1356,6 +1467,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
     else if (n == "squash_base_quals") h->squash_base_quals = value != 0;
     else if (n == "pipeline_pairs") h->pipeline_pairs = std::max<int64_t>(0, static_cast<int64_t>(value));
     else if (n == "pipeline_ramp") h->pipeline_ramp = value != 0;
+    else if (n == "combine_calls") h->combine_calls = value != 0;
     else if (n == "wave_slots") h->wave_slots = std::max(64, static_cast<int>(value));
     else if (n == "stream_lds_floor") h->stream_lds_floor = std::max(0, static_cast<int>(value));
     else if (n == "max_stream_haps") h->max_stream_haps = std::max(1, static_cast<int>(value));

@@ -158,7 +158,12 @@ int gatk_pairhmm_device_count(int32_t* count);
  * gatk_pairhmm_batch), "pipeline_pairs" (default 131072: a compute call with more
  * pairs is cut, between regions and inside a large region between reads, into parts of about that many pairs,
  * and one part is planned and copied while the kernels of the part before it run; 0 = never cut),
- * "pipeline_ramp" (default 1: the first two parts are a quarter and a half of that), and two knobs for occupancy experiments:
+ * "pipeline_ramp" (default 1: the first two parts are a quarter and a half of that),
+ * "combine_calls" (default 0; 1 = gatk_pairhmm_compute_likelihoods calls too small to fill the device, made
+ * at the same time by several threads on their own handles, are scored together: a caller that finds one of
+ * the device's two shared engines free takes every waiting call through one device pass, its own included,
+ * the others wait for their results; same results and exceptions, per caller; only on handles whose other
+ * options are the defaults, squash_base_quals aside), and two knobs for occupancy experiments:
  * "wave_slots" (waves the planner assumes the device holds at once, default 12 per CU) and
  * "stream_lds_floor" (least bytes of LDS a wave of the fp32 stream pass asks for; a larger value
  * lowers the number of waves a CU holds).  Planning options take effect at the next upload or

@@ -56,6 +56,8 @@ extern "C" {
 JNIEXPORT jlong JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniCreate(JNIEnv* env, jclass, jint device) {
     gatk_pairhmm* h = nullptr;
     if (const int rc = gatk_pairhmm_create(device, &h)) { throw_for(env, rc); return 0; }
+    // one PairHMM object per map thread, one region per call: let the calls of all threads share device passes
+    (void)gatk_pairhmm_set_option(h, "combine_calls", 1.0);
     return reinterpret_cast<jlong>(h);
 }
 

@@ -569,10 +569,13 @@ def test_random_shapes_and_options(hmm, oracle, seed):
         assert_parity(g64, want, tol=1e-9)
 
 
-def test_concurrent_handles_one_per_thread(oracle):
+@pytest.mark.parametrize("combine", [False, True])
+def test_concurrent_handles_one_per_thread(oracle, combine):
     """The reference makes one PairHMM per map thread (nanoScheduler/NanoScheduler.java:112, pairhmm/PairHMM.java:297):
     handles used from different threads at the same time must not disturb one another, and a failing call on
-    one thread must leave the other threads' results and error text alone."""
+    one thread must leave the other threads' results and error text alone.  With the handle option
+    combine_calls the region-sized calls of all threads share device passes: a bad batch in a pass fails its
+    own caller only."""
     import threading
 
     regions = synth.make_regions(24, seed=77, coverage=8, read_len=100)
@@ -582,6 +585,8 @@ def test_concurrent_handles_one_per_thread(oracle):
 
     def work(tid):
         h = pairhmm.HipLoglessPairHMM(0)
+        if combine:
+            h.set_option("combine_calls", 1)
         try:
             mine = list(range(tid, len(regions), 4))
             for rep in range(3):

@@ -29,7 +29,7 @@ from gatk_amd import pairhmm, sharding, synth  # noqa: E402
 from gatk_amd.pairhmm import HipLoglessPairHMM  # noqa: E402
 
 
-def score(regions, device, chunk, workers):
+def score(regions, device, chunk, workers, combine=False):
     """Scores regions in chunks on `workers` threads; returns (outs, wall seconds).  The ctypes views of
     the caller's arrays and the output arrays are made beforehand: the clock covers the C-ABI calls."""
     lib = pairhmm.load_library()
@@ -41,6 +41,9 @@ def score(regions, device, chunk, workers):
         arr = (C.c_void_p * len(idx))(*[outs[i].ctypes.data if outs[i].size else None for i in idx])
         calls.append((len(idx), cbs, arr))
     handles = [HipLoglessPairHMM(device) for _ in range(workers)]
+    if combine:  # region-sized calls of all workers share device passes (handle option combine_calls)
+        for h in handles:
+            h.set_option("combine_calls", 1)
     for h in handles:  # an engine in steady state: buffers grown to the largest of these calls, clocks up
         for n, cbs, arr in (calls if workers > 1 else calls[:1]):
             assert lib.gatk_pairhmm_compute_regions(h._h, n, cbs, arr) == 0
@@ -56,7 +59,10 @@ def score(regions, device, chunk, workers):
             if k >= len(calls):
                 return
             n, cbs, arr = calls[k]
-            rc = lib.gatk_pairhmm_compute_regions(h._h, n, cbs, arr)
+            if combine and n == 1:
+                rc = lib.gatk_pairhmm_compute_likelihoods(h._h, C.byref(cbs[0]), arr[0])
+            else:
+                rc = lib.gatk_pairhmm_compute_regions(h._h, n, cbs, arr)
             if rc != 0:
                 errors.append(RuntimeError(lib.gatk_pairhmm_last_error().decode()))
                 return
@@ -85,6 +91,7 @@ def main():
     ap.add_argument("--default-quals", action="store_true",
                     help="pass no insertion / deletion / GCP arrays: the engine's defaults (Q45, Q45, 10), which is what these synthetic reads carry anyway")
     ap.add_argument("--cpu", action="store_true", help="also time the vectorised CPU baseline on the same regions")
+    ap.add_argument("--combine", action="store_true", help="with --chunk 1: one compute_likelihoods call per region with the combine_calls option")
     ap.add_argument("--check", type=int, default=8, help="regions compared with the oracle afterwards")
     args = ap.parse_args()
 
@@ -107,7 +114,7 @@ def main():
     my_regions = [regions[i] for i in mine]
     if group is not None:
         dist.barrier()
-    outs, wall, last = score(my_regions, local_rank, args.chunk, args.workers)
+    outs, wall, last = score(my_regions, local_rank, args.chunk, args.workers, args.combine)
     if group is not None:
         t = [None] * world
         dist.all_gather_object(t, wall)
@@ -126,7 +133,7 @@ def main():
     line = {
         "workload": f"{args.regions} active regions, {args.coverage}x, 151 bp reads (synthetic HaplotypeCaller batch shapes)",
         "reads": int(sum(b.num_reads for b in regions)), "pairs": int(sum(b.num_reads * b.num_haps for b in regions)),
-        "cells": int(cells), "n_gpus": world, "default_indel_and_gcp_arrays": bool(args.default_quals), "chunk_regions": args.chunk, "workers_per_gpu": args.workers,
+        "cells": int(cells), "n_gpus": world, "default_indel_and_gcp_arrays": bool(args.default_quals), "chunk_regions": args.chunk, "workers_per_gpu": args.workers, "combine_calls": bool(args.combine),
         "wall_ms": round(wall * 1e3, 2), "gcups_including_host_and_pcie": round(cells / wall / 1e9, 1),
         "last_call_of_worker_0": {"host_plan_ms": round(last["host_plan_ms"], 2), "host_upload_ms": round(last["host_upload_ms"], 2)},
     }

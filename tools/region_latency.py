@@ -11,9 +11,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gatk_amd import pairhmm, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+options = [a.split("=") for a in sys.argv[2:]]  # engine options as name=value
 regions = synth.make_regions(n, seed=5)
 lib = pairhmm.load_library()
 hmm = pairhmm.HipLoglessPairHMM(0)
+for name, value in options:
+    hmm.set_option(name, float(value))
 keep = []
 calls = []
 for b in regions:
