@@ -582,17 +582,21 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         bk.num_descs = static_cast<int>(R->descs.size()) - bk.desc_begin;
         bk.emit_mode_fp64 = any_hap_n ? kEmitCompareN : kEmitCompare;
         bk.emit_mode = bk.emit_mode_fp64;
+        // Haplotype runs (the stream pass), unless the call is too small to give any wave a run: it then takes
+        // the one-haplotype pass, which writes log10 results itself - one kernel less on a call whose time is
+        // the chain of its launches.
+        const bool runs = h->stream_mode > 0 || (h->stream_mode < 0 && call_pairs >= 2 * static_cast<int64_t>(h->wave_slots));
         if (!any_hap_other && h->emit_mode != 0) {
             const int lut = any_hap_n ? kEmitLut5 : kEmitLut4;
             // a workgroup's LDS must fit the 64 KiB a block may ask for; the stream pass keeps only the table
             // there, the one-haplotype pass also the longest haplotype of the launch
-            const int lds = h->stream_mode != 0 ? stream_lds_bytes_per_wave(K, lut) : lds_bytes_per_wave(K, lut, bk.max_hap_len);
+            const int lds = runs ? stream_lds_bytes_per_wave(K, lut) : lds_bytes_per_wave(K, lut, bk.max_hap_len);
             if (lds * kWavesPerBlock <= 64 * 1024) bk.emit_mode = lut;
         }
         // fp32 stream pass: the haplotype axis of every region is cut into runs; a run is as long as
         // keeps every wave slot of the device supplied twice over, so runs shrink towards the end of
         // the launch and the last waves to finish are short ones
-        bk.stream = (bk.emit_mode == kEmitLut4 || bk.emit_mode == kEmitLut5) && h->stream_mode != 0;
+        bk.stream = (bk.emit_mode == kEmitLut4 || bk.emit_mode == kEmitLut5) && runs;
         const int bucket_index = static_cast<int>(R->buckets.size());
         if (bucket_index >= kMaxBuckets) return fail(GATK_PAIRHMM_ILLEGAL_STATE, "more launch buckets than rows-per-lane choices");
         if (bk.stream) {

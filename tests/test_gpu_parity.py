@@ -58,7 +58,7 @@ def test_config_c1_full(hmm, oracle):
     assert st["pairs"] == 128 * 16 and st["cells"] == b.cells
 
 
-@pytest.mark.parametrize("stream_mode", [-1, 0])
+@pytest.mark.parametrize("stream_mode", [1, 0, -1])
 @pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16])
 def test_every_rows_per_lane_variant(hmm, oracle, k, stream_mode):
     # reads of 1..60 bases (k = 1 needs <= 62 rows); every lane-segment packing is exercised, with
@@ -71,7 +71,7 @@ def test_every_rows_per_lane_variant(hmm, oracle, k, stream_mode):
         assert_parity(hmm.compute_batch(b), want)
     finally:
         hmm.set_option("force_rows_per_lane", 0)
-        hmm.set_option("stream_mode", -1)
+        hmm.set_option("stream_mode", 1)
 
 
 def test_long_read_indel_stress_uses_the_fp64_rerun(hmm, oracle):
@@ -380,7 +380,7 @@ def test_extreme_gap_quality_steps(hmm, oracle):
 # ---- haplotype runs (the fp32 stream pass) ------------------------------------------------------
 
 def with_options(hmm, opts, fn):
-    defaults = {"stream_mode": -1, "max_stream_haps": 16, "force_rows_per_lane": 0, "emit_mode": -1}
+    defaults = {"stream_mode": 1, "max_stream_haps": 16, "force_rows_per_lane": 0, "emit_mode": -1}  # the session handle's
     for k, v in opts.items():
         hmm.set_option(k, v)
     try:
@@ -549,7 +549,7 @@ def test_random_shapes_and_options(hmm, oracle, seed):
             hb[int(rng.integers(len(hb)))] = ord("N")
             b = Batch(b.read_bases, b.read_quals, b.ins_gop, b.del_gop, b.gcp, b.read_offsets, hb, b.hap_offsets)
         regions.append(b)
-    opts = {"stream_mode": int(rng.choice([-1, -1, 0])), "max_stream_haps": int(rng.choice([1, 3, 16])),
+    opts = {"stream_mode": int(rng.choice([1, 1, 0, -1])), "max_stream_haps": int(rng.choice([1, 3, 16])),
             "emit_mode": int(rng.choice([-1, -1, 0]))}
     if rng.random() < 0.4:
         longest = max(int(np.diff(b.read_offsets).max()) for b in regions)
