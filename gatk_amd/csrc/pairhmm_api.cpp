@@ -41,6 +41,7 @@ hipError_t launch_flag_poorly_modelled_reads(const DeviceBatch& B, double maximu
 hipError_t launch_marginalize_reads(const DeviceBatch& B, const int32_t* old_to_new, const int64_t* new_base, const int32_t* new_count,
                                     double* new_out, hipStream_t stream);
 hipError_t launch_prepare(const DeviceBatch& B, bool expand_rows, bool stream, hipStream_t s);
+hipError_t launch_upload(const void* pinned_host, void* device, size_t bytes, hipStream_t s);
 }  // namespace pairhmm_hip
 
 using namespace pairhmm_hip;
@@ -183,6 +184,7 @@ struct gatk_pairhmm {
     int device = 0;
     hipStream_t stream = nullptr;
     int wave_slots = 3072;  // waves the device holds at once at three per SIMD
+    size_t kernel_upload_bytes = size_t{256} << 10;  // uploads up to this size are copied by a kernel, not by the DMA engine
     bool combine_calls = false;  // small compute_likelihoods calls of all threads on this device share device passes
     bool pipeline_ramp = true;  // the first two parts of a cut call are a quarter and a half of pipeline_pairs
     int stream_lds_floor = 0;  // least LDS bytes per wave of the stream pass (caps the waves a CU holds)
@@ -782,7 +784,9 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         HIP_TRY(R->d_raw_out.ensure(std::max<size_t>(static_cast<size_t>(call_pairs) * sizeof(float), 16)));
         HIP_TRY(R->d_pair_lists.ensure(std::max<size_t>(static_cast<size_t>(stream_pairs) * sizeof(RerunPair), 16)));
     }
-    if (upload_bytes) HIP_TRY(hipMemcpyAsync(R->d_arena.p, S, upload_bytes, hipMemcpyHostToDevice, s));
+    // upload_bytes is a multiple of 256 and the staging buffer is at least as large
+    if (upload_bytes > 0 && upload_bytes <= h->kernel_upload_bytes) HIP_TRY(launch_upload(S, R->d_arena.p, upload_bytes, s));
+    else if (upload_bytes) HIP_TRY(hipMemcpyAsync(R->d_arena.p, S, upload_bytes, hipMemcpyHostToDevice, s));
     uint8_t* const Dw = R->d_arena.as<uint8_t>();
     if (!have_ins) HIP_TRY(hipMemsetAsync(Dw + o_ri, kDefaultIndelQual, rbytes + 16, s));
     if (!have_del) HIP_TRY(hipMemsetAsync(Dw + o_rd, kDefaultIndelQual, rbytes + 16, s));
@@ -1472,6 +1476,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
     else if (n == "pipeline_pairs") h->pipeline_pairs = std::max<int64_t>(0, static_cast<int64_t>(value));
     else if (n == "pipeline_ramp") h->pipeline_ramp = value != 0;
     else if (n == "combine_calls") h->combine_calls = value != 0;
+    else if (n == "kernel_upload_bytes") h->kernel_upload_bytes = static_cast<size_t>(std::max(0.0, value));
     else if (n == "wave_slots") h->wave_slots = std::max(64, static_cast<int>(value));
     else if (n == "stream_lds_floor") h->stream_lds_floor = std::max(0, static_cast<int>(value));
     else if (n == "max_stream_haps") h->max_stream_haps = std::max(1, static_cast<int>(value));

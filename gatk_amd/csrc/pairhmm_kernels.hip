@@ -1221,6 +1221,21 @@ hipError_t launch_forward(const DeviceBatch& B, int rows_per_lane, int emit_mode
                 : launch_t<float>(B, rows_per_lane, emit_mode, list_mode, blocks, stream);
 }
 
+// Copies a small upload from pinned host memory (which the device can read) into the arena.  On the
+// stream the kernels run on: a copy through the DMA engine costs its own latency plus a hand-over between
+// engines that is several times the copy itself for a region-sized call.
+__global__ void __launch_bounds__(256) upload_from_host(const uint4* __restrict__ src, uint4* __restrict__ dst, const int n16) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += gridDim.x * blockDim.x) dst[k] = src[k];
+}
+
+hipError_t launch_upload(const void* pinned_host, void* device, size_t bytes, hipStream_t s) {
+    const int n16 = static_cast<int>((bytes + 15) / 16);
+    if (n16 <= 0) return hipSuccess;
+    hipLaunchKernelGGL(upload_from_host, dim3(std::min((n16 + 255) / 256, 512)), dim3(256), 0, s,
+                       static_cast<const uint4*>(pinned_host), static_cast<uint4*>(device), n16);
+    return hipGetLastError();
+}
+
 // expand_rows: write the RowConst entries (the fp32 passes read them); stream: fill the haplotype stream.
 hipError_t launch_prepare(const DeviceBatch& B, bool expand_rows, bool stream, hipStream_t s) {
     const int read_blocks = (B.num_reads + 3) / 4;
