@@ -164,7 +164,9 @@ int gatk_pairhmm_device_count(int32_t* count);
  * at the same time by several threads on their own handles, are scored together: a caller that finds one of
  * the device's two shared engines free takes every waiting call through one device pass, its own included,
  * the others wait for their results; same results and exceptions, per caller; only on handles whose other
- * options are the defaults, squash_base_quals aside), and two knobs for occupancy experiments:
+ * options are the defaults, squash_base_quals aside), "kernel_upload_bytes" (default 262144: an upload of at
+ * most that many bytes is copied out of the pinned staging buffer by a kernel on the compute stream instead
+ * of by the DMA engine, whose hand-over to the first kernel costs more than the copy of a region-sized call), and two knobs for occupancy experiments:
  * "wave_slots" (waves the planner assumes the device holds at once, default 12 per CU) and
  * "stream_lds_floor" (least bytes of LDS a wave of the fp32 stream pass asks for; a larger value
  * lowers the number of waves a CU holds).  Planning options take effect at the next upload or
