@@ -189,33 +189,61 @@ __global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A, const int fir
         p1 = refLength; p2 = altLength;
     } else {
         p2 = altLength;
-        for (int i = 1; i <= refLength; ++i) {
-            const int cur = last_col[i];
-            if (cur >= maxscore) { p1 = i; maxscore = cur; }
+        // the two scans of :362-392, their loads fetched kScan at a time (the comparisons stay in order)
+        constexpr int kScan = 16;
+        for (int i0 = 1; i0 <= refLength; i0 += kScan) {
+            int cur[kScan];
+#pragma unroll
+            for (int q = 0; q < kScan; ++q) cur[q] = i0 + q <= refLength ? last_col[i0 + q] : INT_MIN;
+#pragma unroll
+            for (int q = 0; q < kScan; ++q)
+                if (i0 + q <= refLength && cur[q] >= maxscore) { p1 = i0 + q; maxscore = cur[q]; }
         }
         if (A.strategy != GATK_SW_LEADING_INDEL) {
-            for (int j = 1; j <= altLength; ++j) {
-                const int cur = bottom[j];
-                if (cur > maxscore || (cur == maxscore && abs(refLength - j) < abs(p1 - p2))) {
-                    p1 = refLength; p2 = j; maxscore = cur;
-                    segment_length = altLength - j;
+            for (int j0 = 1; j0 <= altLength; j0 += kScan) {
+                int cur[kScan];
+#pragma unroll
+                for (int q = 0; q < kScan; ++q) cur[q] = j0 + q <= altLength ? bottom[j0 + q] : INT_MIN;
+#pragma unroll
+                for (int q = 0; q < kScan; ++q) {
+                    const int j = j0 + q;
+                    if (j <= altLength && (cur[q] > maxscore || (cur[q] == maxscore && abs(refLength - j) < abs(p1 - p2)))) {
+                        p1 = refLength; p2 = j; maxscore = cur[q];
+                        segment_length = altLength - j;
+                    }
                 }
             }
         }
     }
     if (segment_length > 0 && A.strategy == GATK_SW_SOFTCLIP) { add(GATK_SW_OP_S, segment_length); segment_length = 0; }
     int state = GATK_SW_OP_M;
+    // The walk is a chain of dependent loads, and most of it runs along diagonals (matches): the next
+    // kAhead cells of the diagonal are fetched together, the leading zeros among them are that many match
+    // steps at once, the first non-zero one is a gap handled as in the reference's loop (:401-430).
+    constexpr int kAhead = 8;
     do {
-        const int btr = bt[btrack_index(p1, p2, P.rows_per_lane)];
-        int new_state, step_length = 1;
-        if (btr > 0) { new_state = GATK_SW_OP_D; step_length = btr; }
-        else if (btr < 0) { new_state = GATK_SW_OP_I; step_length = -btr; }
-        else new_state = GATK_SW_OP_M;
-        if (new_state == GATK_SW_OP_M) { --p1; --p2; }
-        else if (new_state == GATK_SW_OP_I) p2 -= step_length;
-        else p1 -= step_length;
-        if (new_state == state) segment_length += step_length;
-        else { add(state, segment_length); segment_length = step_length; state = new_state; }
+        const int span = min(kAhead, min(p1, p2));
+        int ahead[kAhead];
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) ahead[q] = q < span ? bt[btrack_index(p1 - q, p2 - q, P.rows_per_lane)] : 0;
+        int matches = 0, btr = 0;
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q)
+            if (btr == 0 && q < span) {
+                if (ahead[q] == 0) matches = q + 1; else btr = ahead[q];
+            }
+        if (matches > 0) {
+            p1 -= matches; p2 -= matches;
+            if (state == GATK_SW_OP_M) segment_length += matches;
+            else { add(state, segment_length); segment_length = matches; state = GATK_SW_OP_M; }
+        }
+        if (btr != 0) {
+            const int new_state = btr > 0 ? GATK_SW_OP_D : GATK_SW_OP_I;
+            const int step_length = btr > 0 ? btr : -btr;
+            if (new_state == GATK_SW_OP_I) p2 -= step_length; else p1 -= step_length;
+            if (new_state == state) segment_length += step_length;
+            else { add(state, segment_length); segment_length = step_length; state = new_state; }
+        }
     } while (p1 > 0 && p2 > 0);
     int offset;
     if (A.strategy == GATK_SW_SOFTCLIP) {
