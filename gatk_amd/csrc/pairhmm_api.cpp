@@ -208,6 +208,8 @@ struct gatk_pairhmm {
     PinnedBuf stage_in, stage_out;  // pinned staging shared by every upload / download on this handle
     hipEvent_t stage_in_copied = nullptr;  // recorded behind the host-to-device copy out of stage_in
     bool stage_in_busy = false;
+    hipStream_t stage_in_unrecorded = nullptr;  // stream of an upload whose event is still to be recorded
+    bool stage_in_record_due = false;
     std::vector<double> likelihood_array;
     gatk_pairhmm_stats stats{};
     // BatchPairHMM queue: one single-read region per batchAdd
@@ -400,6 +402,18 @@ struct RegionPlan {
     int longest = 0;      // longest read in this plan's wave-groups
     int seg_reads = 0;    // reads in them
 };
+
+// Records the event that guards the staging buffer behind whatever is enqueued on the uploading stream so
+// far.  Later than the copy itself is safe (the next upload waits a little longer); it is called after the
+// kernels of a region-sized pass have been enqueued, so that the record does not delay them.
+int record_stage_in_event(gatk_pairhmm* h) {
+    if (!h->stage_in_record_due) return GATK_PAIRHMM_OK;
+    if (!h->stage_in_copied) HIP_TRY(hipEventCreateWithFlags(&h->stage_in_copied, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->stage_in_copied, h->stage_in_unrecorded));
+    h->stage_in_record_due = false;
+    h->stage_in_busy = true;
+    return GATK_PAIRHMM_OK;
+}
 
 // checked: the caller has run check_region on these regions already (under their own indices)
 int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, const gatk_pairhmm_batch* regions, bool checked = false) {
@@ -705,6 +719,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
                  o_rg = have_gcp ? o_rg_up : L.add(rbytes + 16);
 
     HIP_TRY(hipSetDevice(h->device));
+    if (int rc = record_stage_in_event(h)) return rc;
     if (h->stage_in_busy) {  // the previous upload's copy out of the staging buffer
         HIP_TRY(hipEventSynchronize(h->stage_in_copied));
         h->stage_in_busy = false;
@@ -820,9 +835,9 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     B.num_neg_inf = R->num_neg_inf;
     B.hap_stream_len = static_cast<int32_t>(R->hap_stream_entries);
     // the staging buffer is reused by the next upload on this handle: that upload waits for this copy
-    if (!h->stage_in_copied) HIP_TRY(hipEventCreateWithFlags(&h->stage_in_copied, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(h->stage_in_copied, s));
-    h->stage_in_busy = true;
+    // (the event goes in behind the kernels of the pass when a pass follows at once: record_stage_in_event)
+    h->stage_in_unrecorded = s;
+    h->stage_in_record_due = true;
     R->plan_ms = t_planned - t_begin;
     R->upload_ms = now_ms() - t_planned;
     return GATK_PAIRHMM_OK;
@@ -905,6 +920,7 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
         }
     }
     if (timing) HIP_TRY(hipEventRecord(ev[4], s));
+    if (int rc = record_stage_in_event(h)) return rc;
     // Hand the queued work to the device now: the runtime may otherwise hold launches back until the
     // host next waits on this stream, which in an overlapped call is only after the next part has been planned.
     {
@@ -1496,7 +1512,7 @@ int gatk_pairhmm_upload(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm
         return rc;
     }
     *out = R;
-    return GATK_PAIRHMM_OK;
+    return record_stage_in_event(h);  // no pass follows at once
 }
 
 int gatk_pairhmm_compute_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, int32_t sync) {
