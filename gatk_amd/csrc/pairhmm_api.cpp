@@ -835,9 +835,13 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     B.num_neg_inf = R->num_neg_inf;
     B.hap_stream_len = static_cast<int32_t>(R->hap_stream_entries);
     // the staging buffer is reused by the next upload on this handle: that upload waits for this copy
-    // (the event goes in behind the kernels of the pass when a pass follows at once: record_stage_in_event)
+    // A region-sized upload (the kernel copy above) has its event recorded behind the kernels of the pass that
+    // follows at once, so that the record does not hold them up; behind a large copy it goes in right away:
+    // the next part of an overlapped call must wait for the copy, not for this part's kernels.
     h->stage_in_unrecorded = s;
     h->stage_in_record_due = true;
+    if (upload_bytes > h->kernel_upload_bytes)
+        if (int rc = record_stage_in_event(h)) return rc;
     R->plan_ms = t_planned - t_begin;
     R->upload_ms = now_ms() - t_planned;
     return GATK_PAIRHMM_OK;
