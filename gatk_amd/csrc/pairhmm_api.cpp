@@ -876,7 +876,19 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     B.squash_base_quals = h->squash_base_quals ? 1 : 0;
     B.pair_counts = R->counters() + 1 + kMaxBuckets;
     const bool streaming = R->any_stream && !h->force_fp64;
-    HIP_TRY(launch_prepare(B, !h->force_fp64, streaming, s));
+    // A region-sized call on the one-haplotype pass skips the expansion launch: the forward kernel works the
+    // row constants out itself (and makes the quality checks), one launch less in a chain of five.
+    const bool rows_in_kernel = !streaming && !h->force_fp64 && R->total_pairs < 2 * static_cast<int64_t>(h->wave_slots);
+    if (rows_in_kernel) {
+        B.row_consts = nullptr;
+        if (R->num_neg_inf > 0) {  // only the -infinity fill of zero-length reads is left of the prepare pass
+            DeviceBatch P = B;
+            P.num_reads = 0;
+            HIP_TRY(launch_prepare(P, false, false, s));
+        }
+    } else {
+        HIP_TRY(launch_prepare(B, !h->force_fp64, streaming, s));
+    }
     if (timing) HIP_TRY(hipEventRecord(ev[1], s));
     auto bucket_args = [&](size_t bi, int mode) {
         const Bucket& bk = R->buckets[bi];

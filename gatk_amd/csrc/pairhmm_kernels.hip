@@ -174,6 +174,50 @@ struct LaneInfo {
     int seg_last;   // 1 if this lane holds the read's last row
 };
 
+// Entry i of a read's RowConst list (0: the pad row above row 1, 1..R: the read's rows, R + 1: the sum row)
+// from the quality bytes, with the checks the reference makes while expanding a read's qualities
+// (PairHMMModel.java:136-138: negative ins/del/GCP byte -> IllegalArgumentException, bit 0 of `bad`;
+// QualityUtils.java:173: base quality 255 indexes past the 255-entry cache, bit 1).  The arithmetic is done
+// in double and rounded once (PairHMMModel.java:109-143 for the transitions, QualityUtils.java:169-176 for
+// the priors).
+__device__ __forceinline__ RowConst make_row_const(const DeviceBatch& B, const int read, const int ro, const int R, const int i, int& bad) {
+    RowConst c{0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, kNoBase, 0u};
+    double t2 = 0.0, t4 = 1.0;  // a pad row hands its deletion mass down unweighted
+    if (i >= 1 && i <= R) {
+        const unsigned x = B.read_bases[ro + i - 1];
+        const unsigned ins_byte = B.ins_gop[ro + i - 1], del_byte = B.del_gop[ro + i - 1], gcp_byte = B.gcp[ro + i - 1];
+        if ((ins_byte | del_byte | gcp_byte) & 0x80u) bad |= 1;
+        if (B.read_quals[ro + i - 1] == 255) bad |= 2;
+        const double e = B.err_prob[effective_qual(B, ro + i - 1, read)];
+        const unsigned ins = ins_byte & 127u, del = del_byte & 127u;
+        const double t0 = B.match_to_match[ins * 128u + del];
+        const double p = 1.0 - e;
+        const double q = (x == 'N') ? p : e / 3.0;  // a read 'N' matches every base
+        t2 = B.err_prob[ins];
+        t4 = B.err_prob[del];
+        c.p_match = static_cast<float>(p * t0);
+        c.p_mismatch = static_cast<float>(q * t0);
+        c.t5 = static_cast<float>(B.err_prob[gcp_byte]);
+        c.base = x;
+    }
+    if (i < R) {  // transitions of read row i + 1, taken from quals[i]
+        const unsigned ins = B.ins_gop[ro + i] & 127u, del = B.del_gop[ro + i] & 127u;
+        const double eg = B.err_prob[B.gcp[ro + i]];
+        const double t0n = B.match_to_match[ins * 128u + del];
+        const double t1n = 1.0 - eg;
+        if (i >= 1) {
+            c.c_f = static_cast<float>(t2 * eg / B.err_prob[ins]);
+            c.c_i = static_cast<float>(t2 * t1n / t0n);
+        }
+        c.c_e = static_cast<float>(t4 * t1n / t0n);
+    } else if (i == R) {
+        c.c_i = static_cast<float>(t2);  // last row: Sn = M + F * t2 = M + I, what the sum row adds up
+    } else {
+        c.p_match = c.p_mismatch = 1.0f;  // sum row
+    }
+    return c;
+}
+
 template <typename T, int K, int MODE>
 __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_idx, unsigned char* slice,
                                          const int lane, const bool queue_underflow) {
@@ -261,13 +305,29 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
         // load of the lane in flight at once
         const int rc_base = ro + 2 * (ld.read_idx >= 0 ? ld.read_idx : 0);
         float4 c0[K], c1[K];
+        if (B.row_consts != nullptr) {
 #pragma unroll
-        for (int r = 0; r < K; ++r) {
-            int e = ld.first_row + r;
-            e = e < 0 ? 0 : (e > R + 1 ? R + 1 : e);
-            const float4* src = reinterpret_cast<const float4*>(B.row_consts + rc_base + e);
-            c0[r] = src[0];
-            c1[r] = src[1];
+            for (int r = 0; r < K; ++r) {
+                int e = ld.first_row + r;
+                e = e < 0 ? 0 : (e > R + 1 ? R + 1 : e);
+                const float4* src = reinterpret_cast<const float4*>(B.row_consts + rc_base + e);
+                c0[r] = src[0];
+                c1[r] = src[1];
+            }
+        } else {
+            // a region-sized call: no expansion pass ran, the same entries are worked out here (and the
+            // quality checks with them)
+            int bad = 0;
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                int e = ld.first_row + r;
+                e = e < 0 ? 0 : (e > R + 1 ? R + 1 : e);
+                RowConst c{0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, kNoBase, 0u};
+                if (ld.read_idx >= 0) c = make_row_const(B, ld.read_idx, ro, R, e, bad);
+                c0[r] = make_float4(c.p_match, c.p_mismatch, c.t5, c.c_f);
+                c1[r] = make_float4(c.c_i, c.c_e, __uint_as_float(c.base), 0.0f);
+            }
+            if (bad) atomicOr(B.error_word, bad);
         }
 #pragma unroll
         for (int r = 0; r < K; ++r) {
@@ -1016,40 +1076,7 @@ __device__ __forceinline__ void prepare_read(const DeviceBatch& B, const int rea
     RowConst* dst = B.row_consts + ro + 2 * static_cast<int64_t>(read);
     int bad = 0;
     for (int i = lane; i <= R + 1; i += kWave) {
-        RowConst c{0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, kNoBase, 0u};
-        double t2 = 0.0, t4 = 1.0;  // a pad row hands its deletion mass down unweighted
-        if (i >= 1 && i <= R) {
-            const unsigned x = B.read_bases[ro + i - 1];
-            const unsigned ins_byte = B.ins_gop[ro + i - 1], del_byte = B.del_gop[ro + i - 1], gcp_byte = B.gcp[ro + i - 1];
-            if ((ins_byte | del_byte | gcp_byte) & 0x80u) bad |= 1;
-            if (B.read_quals[ro + i - 1] == 255) bad |= 2;
-            const double e = B.err_prob[effective_qual(B, ro + i - 1, read)];
-            const unsigned ins = ins_byte & 127u, del = del_byte & 127u;
-            const double t0 = B.match_to_match[ins * 128u + del];
-            const double p = 1.0 - e;
-            const double q = (x == 'N') ? p : e / 3.0;  // a read 'N' matches every base
-            t2 = B.err_prob[ins];
-            t4 = B.err_prob[del];
-            c.p_match = static_cast<float>(p * t0);
-            c.p_mismatch = static_cast<float>(q * t0);
-            c.t5 = static_cast<float>(B.err_prob[gcp_byte]);
-            c.base = x;
-        }
-        if (i < R) {  // transitions of read row i + 1, taken from quals[i]
-            const unsigned ins = B.ins_gop[ro + i] & 127u, del = B.del_gop[ro + i] & 127u;
-            const double eg = B.err_prob[B.gcp[ro + i]];
-            const double t0n = B.match_to_match[ins * 128u + del];
-            const double t1n = 1.0 - eg;
-            if (i >= 1) {
-                c.c_f = static_cast<float>(t2 * eg / B.err_prob[ins]);
-                c.c_i = static_cast<float>(t2 * t1n / t0n);
-            }
-            c.c_e = static_cast<float>(t4 * t1n / t0n);
-        } else if (i == R) {
-            c.c_i = static_cast<float>(t2);  // last row: Sn = M + F * t2 = M + I, what the sum row adds up
-        } else {
-            c.p_match = c.p_mismatch = 1.0f;  // sum row
-        }
+        const RowConst c = make_row_const(B, read, ro, R, i, bad);
         if (expand) dst[i] = c;
     }
     if (bad) atomicOr(B.error_word, bad);

@@ -612,3 +612,45 @@ def test_concurrent_handles_one_per_thread(oracle, combine):
     for t in threads:
         t.join()
     assert not failures, failures
+
+
+def test_region_sized_call_on_a_default_handle(oracle):
+    """Left to itself (stream_mode -1) the engine gives a region-sized call to the one-haplotype pass and lets
+    that kernel expand the reads and check the qualities itself: parity, the -infinity of zero-length reads,
+    missing optional arrays, the mapping-quality cap with squashing, the reference's two input exceptions and
+    a pair that needs the fp64 rerun, all on that path."""
+    h = pairhmm.HipLoglessPairHMM(0)
+    try:
+        b = synth.make_regions(1, seed=91, coverage=12, read_len=110)[0]
+        assert_parity(h.compute_batch(b), ref(oracle, b))
+        # zero-length read next to ordinary ones, no insertion / deletion / GCP arrays
+        z = pack([("", [], None, None, None), ("ACGTACGT", [30] * 8, None, None, None), ("TTGCA", [20] * 5, None, None, None)], ["ACGTACGTAC", "TTGCATT"])
+        got = h.compute_batch(z)
+        zd = pack([("", [], [], [], []), ("ACGTACGT", [30] * 8, [45] * 8, [45] * 8, [10] * 8), ("TTGCA", [20] * 5, [45] * 5, [45] * 5, [10] * 5)], ["ACGTACGTAC", "TTGCATT"])
+        want = ref(oracle, zd)
+        assert np.isneginf(got[0]).all() and np.abs(got[1:] - want[1:]).max() <= TOL
+        # mapping-quality cap and squashing
+        m = synth.make_batch(30, 4, 90, 250, seed=92, mean_qual=22.0)
+        mapq = (np.arange(m.num_reads) % 4 * 15 + 5).astype(np.uint8)
+        quals = m.read_quals.copy()
+        for r in range(m.num_reads):
+            lo, hi = m.read_offsets[r], m.read_offsets[r + 1]
+            quals[lo:hi] = oracle.modify_read_qualities(quals[lo:hi], mapq[r], True)
+        h.set_option("squash_base_quals", 1)
+        got = h.compute_batch(Batch(m.read_bases, m.read_quals, m.ins_gop, m.del_gop, m.gcp, m.read_offsets, m.hap_bases, m.hap_offsets, mapq))
+        h.set_option("squash_base_quals", 0)
+        assert_parity(got, ref(oracle, Batch(m.read_bases, quals, m.ins_gop, m.del_gop, m.gcp, m.read_offsets, m.hap_bases, m.hap_offsets)))
+        # the two input exceptions, then a good call on the same handle
+        ok = ("ACGT", [30] * 4, [45] * 4, [45] * 4, [10] * 4)
+        with pytest.raises(pairhmm.IllegalArgumentException):
+            h.compute_batch(pack([("ACGT", [30] * 4, [45, 200, 45, 45], [45] * 4, [10] * 4)], ["ACGTA"]))
+        with pytest.raises(pairhmm.ArrayIndexOutOfBoundsException):
+            h.compute_batch(pack([("ACGT", [30, 255, 30, 30], [45] * 4, [45] * 4, [10] * 4)], ["ACGTA"]))
+        assert np.isfinite(h.compute_batch(pack([ok], ["ACGTA"]))).all()
+        # a read far from its haplotype at high quality: fp32 gives up, the rerun list carries it
+        far = synth.config_c5(num_reads=96, num_haps=12)
+        got = h.compute_batch(far)
+        assert h.stats()["rerun_tasks"] > 0
+        assert_parity(got, ref(oracle, far))
+    finally:
+        h.close()
