@@ -185,6 +185,7 @@ struct gatk_pairhmm {
     hipStream_t stream = nullptr;
     int wave_slots = 3072;  // waves the device holds at once at three per SIMD
     size_t kernel_upload_bytes = size_t{256} << 10;  // uploads up to this size are copied by a kernel, not by the DMA engine
+    int64_t per_group_factor = 32;  // calls with at least this many pairs per wave slot choose rows per lane per wave-group
     bool combine_calls = false;  // small compute_likelihoods calls of all threads on this device share device passes
     bool pipeline_ramp = true;  // the first two parts of a cut call are a quarter and a half of pipeline_pairs
     int stream_lds_floor = 0;  // least LDS bytes per wave of the stream pass (caps the waves a CU holds)
@@ -264,6 +265,34 @@ int choose_rows_per_lane(const std::vector<int>& lens_desc, int64_t num_haps, do
         if (t < best * 0.99) { best = t; best_k = k; }
     }
     return best_k;
+}
+
+// Rows per lane for a whole call that is too small to keep the device busy for long: one value for every
+// region, because every value in use costs a launch of its own whose waves run from start to end with the
+// device partly empty.  Measured on calls of 1 to 128 HaplotypeCaller-sized regions: while the call's work
+// items (one wave-group on one haplotype) number at most two per SIMD, a wave issues at the rate of a wave
+// alone, so the value with the shortest wave wins, which is the smallest that still has so few items; once
+// no value has so few, the one with the fewest vector instructions in total wins.
+struct RegionShape { int num_reads, num_haps; double packing_read_len, mean_hap_len; };
+int choose_call_rows_per_lane(const std::vector<RegionShape>& shapes, int longest_read) {
+    const int min_k = (longest_read + 1 + kWave) / kWave;
+    int best_k = 0;
+    double best = std::numeric_limits<double>::infinity();
+    for (int k : kRowsPerLaneChoices) {
+        if (k < min_k) continue;
+        if (k > 12 && best_k != 0) break;  // more rows cost a wave per SIMD: only for long reads
+        double items = 0, work = 0;
+        for (const RegionShape& r : shapes) {
+            const int seg = static_cast<int>((r.packing_read_len + 1 + k) / k);
+            const int per_wave = std::max(1, kWave / std::max(seg, 1));
+            const double w = static_cast<double>((r.num_reads + per_wave - 1) / per_wave) * r.num_haps;
+            items += w;
+            work += w * (r.mean_hap_len + seg + 1) * (5.0 * k + 6.0);
+        }
+        if (items <= 2.1 * 1024) return k;
+        if (work < best * 0.99) { best = work; best_k = k; }
+    }
+    return best_k != 0 ? best_k : kMaxRowsPerLane;
 }
 
 // Rows per lane for a wave-group whose longest read has `longest` bases, in a call large enough to keep the
@@ -446,6 +475,31 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     if (call_pairs >= (int64_t{1} << 31) || total_read_bytes >= (int64_t{1} << 31) || hap_pool_bytes >= (int64_t{1} << 31))
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "more than 2^31 pairs or bytes in one call");
 
+    // a call that does not fill the device for long: one rows-per-lane value for all of it
+    int call_k = h->force_rows_per_lane;
+    if (call_k == 0 && call_pairs > 0 && call_pairs < h->per_group_factor * static_cast<int64_t>(h->wave_slots)) {
+        std::vector<RegionShape> shapes;
+        shapes.reserve(num_regions);
+        int longest = 1;
+        for (int k = 0; k < num_regions; ++k) {
+            const gatk_pairhmm_batch& b = regions[k];
+            if (b.num_reads == 0 || b.num_haps == 0) continue;
+            int nonempty = 0, region_longest = 0;
+            for (int r = 0; r < b.num_reads; ++r) {
+                const int len = b.read_offsets[r + 1] - b.read_offsets[r];
+                region_longest = std::max(region_longest, len);
+                nonempty += len > 0;
+            }
+            if (nonempty == 0) continue;
+            longest = std::max(longest, region_longest);
+            // reads are packed longest first: between the mean and the longest is what decides how many share a wave
+            const double mean_len = static_cast<double>(b.read_offsets[b.num_reads] - b.read_offsets[0]) / nonempty;
+            shapes.push_back(RegionShape{nonempty, b.num_haps, 0.5 * (mean_len + region_longest),
+                                         static_cast<double>(b.hap_offsets[b.num_haps] - b.hap_offsets[0]) / b.num_haps});
+        }
+        call_k = choose_call_rows_per_lane(shapes, longest);
+    }
+
     std::vector<RegionPlan> plans;
     plans.reserve(num_regions);
     std::vector<GroupDesc> groups;
@@ -511,12 +565,12 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
                 lens_desc[at] = len;
             }
         }
-        // Rows per lane: one value for the region when the call is too small to fill the device (the model
-        // then trades instruction count against waves in flight); otherwise every wave-group takes the
-        // value that suits its own reads, so a region whose reads differ in length spreads over buckets.
+        // Rows per lane: the call's value (or the forced one; a region whose reads are too long for it gets
+        // one of its own from the region model); in a large call every wave-group takes the value that
+        // suits its own reads, so a region whose reads differ in length spreads over buckets.
         const double mean_hap = static_cast<double>(hap_total) / nh;
-        const bool per_group = h->force_rows_per_lane == 0 && call_pairs >= 4 * static_cast<int64_t>(h->wave_slots);
-        const int region_k = per_group ? 0 : choose_rows_per_lane(lens_desc, nh, mean_hap, call_pairs, h->force_rows_per_lane);
+        const bool per_group = call_k == 0;
+        const int region_k = per_group ? 0 : choose_rows_per_lane(lens_desc, nh, mean_hap, call_pairs, call_k);
         size_t pos = 0;
         while (pos < order.size()) {
             const int K = per_group ? choose_group_rows_per_lane(lens_desc[pos]) : region_k;
@@ -1508,6 +1562,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
     else if (n == "pipeline_pairs") h->pipeline_pairs = std::max<int64_t>(0, static_cast<int64_t>(value));
     else if (n == "pipeline_ramp") h->pipeline_ramp = value != 0;
     else if (n == "combine_calls") h->combine_calls = value != 0;
+    else if (n == "per_group_factor") h->per_group_factor = std::max<int64_t>(1, static_cast<int64_t>(value));
     else if (n == "kernel_upload_bytes") h->kernel_upload_bytes = static_cast<size_t>(std::max(0.0, value));
     else if (n == "wave_slots") h->wave_slots = std::max(64, static_cast<int>(value));
     else if (n == "stream_lds_floor") h->stream_lds_floor = std::max(0, static_cast<int>(value));
