@@ -50,6 +50,15 @@ namespace {
 
 thread_local std::string g_last_error;
 std::atomic<int> g_num_threads{1};
+// compute_regions calls under way per device (all handles): a call that has the device to itself overlaps
+// its own halves; one that shares it is overlapped with the calls of the other handles already
+std::atomic<int> g_region_calls[64];
+struct RegionCallCount {
+    std::atomic<int>& n;
+    int others;
+    explicit RegionCallCount(int device) : n(g_region_calls[device & 63]), others(n.fetch_add(1)) {}
+    ~RegionCallCount() { n.fetch_sub(1); }
+};
 
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
@@ -206,6 +215,7 @@ struct gatk_pairhmm {
     gatk_pairhmm_resident scratch, scratch2;
     hipStream_t stream2 = nullptr;
     int64_t pipeline_pairs = 131072;  // pairs per part of such a call; 0: never split a call
+    int64_t pipeline_min_pairs = 12288;  // the halves of a call with less than two parts' worth of pairs are at least this large
     PinnedBuf stage_in, stage_out;  // pinned staging shared by every upload / download on this handle
     hipEvent_t stage_in_copied = nullptr;  // recorded behind the host-to-device copy out of stage_in
     bool stage_in_busy = false;
@@ -1184,6 +1194,7 @@ int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gat
     if (num_regions < 0 || (num_regions > 0 && !regions)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "regions cannot be null");
     for (int k = 0; k < num_regions; ++k)
         if (int rc = check_region(regions[k], k)) return rc;
+    const RegionCallCount in_flight(h->device);
     // A region with more pairs than a part holds is cut by read ranges (its pairs are independent,
     // PairHMM.java:217): the pieces share its haplotypes and write into consecutive rows of its array.
     std::vector<gatk_pairhmm_batch> pieces;
@@ -1219,15 +1230,23 @@ int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gat
     // so that the device starts early (nothing overlaps the planning of the first part)
     std::vector<int> cuts{0};
     if (h->pipeline_pairs > 0) {
-        int64_t acc = 0, total = 0;
+        int64_t acc = 0, total = 0, taken = 0;
         for (int k = 0; k < num_regions; ++k)
             if (regions[k].num_reads > 0 && regions[k].num_haps > 0) total += static_cast<int64_t>(regions[k].num_reads) * regions[k].num_haps;
-        const bool ramp = h->pipeline_ramp && total >= 3 * h->pipeline_pairs;
+        // a call of less than two parts' worth is cut in two halves, down to pipeline_min_pairs each, so that
+        // the planning of the second half and the copy back of the first hide behind kernels
+        const int64_t part_pairs = in_flight.others > 0 ? h->pipeline_pairs
+                                 : std::max(std::min(h->pipeline_min_pairs, h->pipeline_pairs), std::min(h->pipeline_pairs, total / 2));
+        const bool ramp = h->pipeline_ramp && total >= 3 * part_pairs;
         for (int k = 0; k < num_regions; ++k) {
-            if (regions[k].num_reads > 0 && regions[k].num_haps > 0) acc += static_cast<int64_t>(regions[k].num_reads) * regions[k].num_haps;
+            if (regions[k].num_reads > 0 && regions[k].num_haps > 0) {
+                const int64_t pairs = static_cast<int64_t>(regions[k].num_reads) * regions[k].num_haps;
+                acc += pairs; taken += pairs;
+            }
             const size_t part = cuts.size() - 1;
-            const int64_t want = !ramp || part >= 2 ? h->pipeline_pairs : h->pipeline_pairs >> (2 - part);
-            if (acc >= want && k + 1 < num_regions) { cuts.push_back(k + 1); acc = 0; }
+            const int64_t want = !ramp || part >= 2 ? part_pairs : part_pairs >> (2 - part);
+            // no cut that leaves less than half a part behind it
+            if (acc >= want && k + 1 < num_regions && 2 * (total - taken) >= part_pairs) { cuts.push_back(k + 1); acc = 0; }
         }
     }
     cuts.push_back(num_regions);
@@ -1561,6 +1580,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
     else if (n == "squash_base_quals") h->squash_base_quals = value != 0;
     else if (n == "pipeline_pairs") h->pipeline_pairs = std::max<int64_t>(0, static_cast<int64_t>(value));
     else if (n == "pipeline_ramp") h->pipeline_ramp = value != 0;
+    else if (n == "pipeline_min_pairs") h->pipeline_min_pairs = std::max<int64_t>(1, static_cast<int64_t>(value));
     else if (n == "combine_calls") h->combine_calls = value != 0;
     else if (n == "per_group_factor") h->per_group_factor = std::max<int64_t>(1, static_cast<int64_t>(value));
     else if (n == "kernel_upload_bytes") h->kernel_upload_bytes = static_cast<size_t>(std::max(0.0, value));
