@@ -654,3 +654,30 @@ def test_region_sized_call_on_a_default_handle(oracle):
         assert_parity(got, ref(oracle, far))
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("num_regions", [10, 40, 70])
+def test_mid_sized_calls_on_a_default_handle(oracle, num_regions):
+    """Calls of some thousand to some ten thousand pairs on a handle with default options: one rows-per-lane
+    value for the whole call, and from 24 576 pairs on two overlapped halves.  Regions with reads of different
+    lengths, an empty region and a zero-length read among them; same results as with one region per call."""
+    regions = synth.make_regions(num_regions, seed=300 + num_regions, coverage=30, read_len=151)
+    regions += synth.make_regions(3, seed=17, coverage=10, read_len=60)
+    regions.insert(2, pack([], ["ACGTACGT"]))
+    regions.append(pack([("", [], [], [], []), ("ACGTTGCA", [30] * 8, [45] * 8, [45] * 8, [10] * 8)], ["ACGTTGCAAC", "ACGTGCAAC"]))
+    h = pairhmm.HipLoglessPairHMM(0)
+    try:
+        got = h.compute_regions(regions)
+        st = h.stats()
+        assert st["pairs"] == sum(b.num_reads * b.num_haps for b in regions)
+        for k in list(range(0, len(regions), 9)) + [len(regions) - 1]:
+            if regions[k].num_reads:
+                assert_parity(got[k], ref(oracle, regions[k], threads=2))
+        for k, b in enumerate(regions):
+            one = h.compute_batch(b) if b.num_reads else np.empty((0, b.num_haps))
+            fin = np.isfinite(one)
+            assert np.array_equal(np.isfinite(got[k]), fin)
+            assert np.abs(got[k][fin] - one[fin]).max(initial=0.0) <= 2e-6
+        assert np.isneginf(got[-1][0]).all()
+    finally:
+        h.close()
