@@ -3,7 +3,8 @@
 // batches (empty regions, zero-length reads, missing optional arrays, 'N' bases, mapping-quality caps, a few
 // reads that underflow fp32) through every entry point and checks that differently planned engine
 // configurations agree: automatic planning against forced rows per lane with one haplotype per work item,
-// one big call against region-at-a-time calls, host-pointer calls against the resident path.
+// one big call against region-at-a-time calls and against calls of a few dozen regions on a default handle,
+// host-pointer calls against the resident path.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -173,6 +174,26 @@ int main(int argc, char** argv) {
     { auto p = pointers(merged); CHECK(gatk_pairhmm_marginalize_resident(h3, res, map_ptrs.data(), new_counts.data(), p.data())); }
     CHECK(gatk_pairhmm_normalize_resident(h3, res, nullptr, 1, -4.5));
     CHECK(gatk_pairhmm_resident_free(h3, res));
+
+    // default options: one call over everything, then calls of 1 to 80 regions (one rows-per-lane value per
+    // call, two overlapped halves from some ten thousand pairs on)
+    gatk_pairhmm* h4 = nullptr;
+    CHECK(gatk_pairhmm_create(0, &h4));
+    auto dflt = outputs();
+    { auto p = pointers(dflt); CHECK(gatk_pairhmm_compute_regions(h4, num_regions, batches.data(), p.data())); }
+    const double d3 = worst_difference(all, dflt);
+    auto mid = outputs();
+    {
+        auto p = pointers(mid);
+        for (int at = 0; at < num_regions;) {
+            const int n = std::min(num_regions - at, g.range(1, 80));
+            CHECK(gatk_pairhmm_compute_regions(h4, n, batches.data() + at, p.data() + at));
+            at += n;
+        }
+    }
+    const double d4 = worst_difference(all, mid);
+    CHECK(gatk_pairhmm_close(h4));
+    if (!(d3 <= 2e-3) || !(d4 <= 2e-3)) { std::printf("default handle differs: %g %g\nFAILED\n", d3, d4); return 1; }
 
     // the queueing interface and the single-pair call on the first region that has a read
     for (auto& r : regions) {
