@@ -29,7 +29,7 @@ from gatk_amd import pairhmm, sharding, synth  # noqa: E402
 from gatk_amd.pairhmm import HipLoglessPairHMM  # noqa: E402
 
 
-def score(regions, device, chunk, workers, combine=False):
+def score(regions, device, chunk, workers, combine=False, options=()):
     """Scores regions in chunks on `workers` threads; returns (outs, wall seconds).  The ctypes views of
     the caller's arrays and the output arrays are made beforehand: the clock covers the C-ABI calls."""
     lib = pairhmm.load_library()
@@ -41,6 +41,9 @@ def score(regions, device, chunk, workers, combine=False):
         arr = (C.c_void_p * len(idx))(*[outs[i].ctypes.data if outs[i].size else None for i in idx])
         calls.append((len(idx), cbs, arr))
     handles = [HipLoglessPairHMM(device) for _ in range(workers)]
+    for h in handles:
+        for name, value in options:
+            h.set_option(name, value)
     if combine:  # region-sized calls of all workers share device passes (handle option combine_calls)
         for h in handles:
             h.set_option("combine_calls", 1)
@@ -92,6 +95,7 @@ def main():
                     help="pass no insertion / deletion / GCP arrays: the engine's defaults (Q45, Q45, 10), which is what these synthetic reads carry anyway")
     ap.add_argument("--cpu", action="store_true", help="also time the vectorised CPU baseline on the same regions")
     ap.add_argument("--combine", action="store_true", help="with --chunk 1: one compute_likelihoods call per region with the combine_calls option")
+    ap.add_argument("--option", action="append", default=[], help="engine option as name=value (repeatable)")
     ap.add_argument("--check", type=int, default=8, help="regions compared with the oracle afterwards")
     args = ap.parse_args()
 
@@ -114,7 +118,7 @@ def main():
     my_regions = [regions[i] for i in mine]
     if group is not None:
         dist.barrier()
-    outs, wall, last = score(my_regions, local_rank, args.chunk, args.workers, args.combine)
+    outs, wall, last = score(my_regions, local_rank, args.chunk, args.workers, args.combine, [(o.split("=")[0], float(o.split("=")[1])) for o in args.option])
     if group is not None:
         t = [None] * world
         dist.all_gather_object(t, wall)
