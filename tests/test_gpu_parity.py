@@ -659,7 +659,7 @@ def test_region_sized_call_on_a_default_handle(oracle):
 @pytest.mark.parametrize("num_regions", [10, 40, 70])
 def test_mid_sized_calls_on_a_default_handle(oracle, num_regions):
     """Calls of some thousand to some ten thousand pairs on a handle with default options: one rows-per-lane
-    value for the whole call, and from 24 576 pairs on two overlapped halves.  Regions with reads of different
+    value for the whole call, and from about 18 000 pairs on two overlapped halves.  Regions with reads of different
     lengths, an empty region and a zero-length read among them; same results as with one region per call."""
     regions = synth.make_regions(num_regions, seed=300 + num_regions, coverage=30, read_len=151)
     regions += synth.make_regions(3, seed=17, coverage=10, read_len=60)
