@@ -212,8 +212,9 @@ struct gatk_pairhmm {
     bool timing = false;
     // buffers reused by the host-pointer entry points; two of them, each with a stream of its own, so that
     // a call over many regions can plan and copy one part while the kernels of the part before it run
-    gatk_pairhmm_resident scratch, scratch2;
-    hipStream_t stream2 = nullptr;
+    gatk_pairhmm_resident scratch, scratch2, scratch3;
+    hipStream_t stream2 = nullptr, stream3 = nullptr;
+    int pipeline_depth = 3;  // parts of a cut call in flight or in planning at once (2 or 3)
     int64_t pipeline_pairs = 131072;  // pairs per part of such a call; 0: never split a call
     int64_t pipeline_min_pairs = 12288;  // the halves of a call with less than two parts' worth of pairs are at least this large
     PinnedBuf stage_in, stage_out;  // pinned staging shared by every upload / download on this handle
@@ -1161,6 +1162,7 @@ int gatk_pairhmm_create(int device, gatk_pairhmm** out) {
     h->device = device;
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking);
     int cus = 0;
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (cus > 0) h->wave_slots = cus * 12;
@@ -1260,12 +1262,16 @@ int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gat
     // kernels of part p + 1 run
     h->scratch.stream = h->stream;
     h->scratch2.stream = h->stream2;
-    gatk_pairhmm_resident* slot[2] = {&h->scratch, &h->scratch2};
+    h->scratch3.stream = h->stream3;
+    gatk_pairhmm_resident* slot[3] = {&h->scratch, &h->scratch2, &h->scratch3};
+    // depth 3: the host plans part p + 2 without waiting for part p first, so that the device always has a
+    // whole part queued behind the one it is working on
+    const int depth = h->pipeline_depth >= 3 ? 3 : 2;
     gatk_pairhmm_stats total{};
     int rc = GATK_PAIRHMM_OK;
     const int parts = static_cast<int>(cuts.size()) - 1;
     auto fetch = [&](int p) {
-        gatk_pairhmm_resident* R = slot[p & 1];
+        gatk_pairhmm_resident* R = slot[p % depth];
         const int r = R->total_pairs > 0 ? download_into(h, R, likelihoods ? likelihoods + cuts[p] : nullptr) : GATK_PAIRHMM_OK;
         if (R->total_pairs > 0) {
             const gatk_pairhmm_stats& st = h->stats;
@@ -1280,17 +1286,18 @@ int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gat
     int fetched = 0;  // parts [0, fetched) are done; parts [fetched, enqueued) are in flight
     int enqueued = 0;
     for (int p = 0; p < parts && rc == GATK_PAIRHMM_OK; ++p) {
-        gatk_pairhmm_resident* R = slot[p & 1];
+        gatk_pairhmm_resident* R = slot[p % depth];
         rc = plan_and_upload(h, R, cuts[p + 1] - cuts[p], regions + cuts[p], true);
         if (rc == GATK_PAIRHMM_OK && R->total_pairs > 0) rc = enqueue_compute(h, R);
         if (rc == GATK_PAIRHMM_OK) enqueued = p + 1;
-        if (rc == GATK_PAIRHMM_OK && p >= 1) { rc = fetch(p - 1); fetched = p; }
+        if (rc == GATK_PAIRHMM_OK && p >= depth - 1) { rc = fetch(p - (depth - 1)); fetched = p - (depth - 1) + 1; }
     }
-    if (rc == GATK_PAIRHMM_OK && fetched < enqueued) { rc = fetch(enqueued - 1); fetched = enqueued; }
+    while (rc == GATK_PAIRHMM_OK && fetched < enqueued) { rc = fetch(fetched); ++fetched; }
     if (rc != GATK_PAIRHMM_OK) {  // leave nothing in flight on buffers the next call will reuse
         const std::string msg = g_last_error;
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamSynchronize(h->stream2);
+        (void)hipStreamSynchronize(h->stream3);
         for (auto* R : slot) {
             for (auto& ev : R->ev_pending) R->ev_free.push_back(ev);
             R->ev_pending.clear();
@@ -1547,8 +1554,10 @@ int gatk_pairhmm_close(gatk_pairhmm* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    if (h->stream3) (void)hipStreamSynchronize(h->stream3);
     h->scratch.release();
     h->scratch2.release();
+    h->scratch3.release();
     if (h->stage_in_copied) { (void)hipEventSynchronize(h->stage_in_copied); (void)hipEventDestroy(h->stage_in_copied); }
     h->stage_in.release();
     h->stage_out.release();
@@ -1556,6 +1565,7 @@ int gatk_pairhmm_close(gatk_pairhmm* h) {
     if (h->d_mm) (void)hipFree(h->d_mm);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    if (h->stream3) (void)hipStreamDestroy(h->stream3);
     delete h;
     return GATK_PAIRHMM_OK;
 }
@@ -1580,6 +1590,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
     else if (n == "squash_base_quals") h->squash_base_quals = value != 0;
     else if (n == "pipeline_pairs") h->pipeline_pairs = std::max<int64_t>(0, static_cast<int64_t>(value));
     else if (n == "pipeline_ramp") h->pipeline_ramp = value != 0;
+    else if (n == "pipeline_depth") h->pipeline_depth = value >= 3 ? 3 : 2;
     else if (n == "pipeline_min_pairs") h->pipeline_min_pairs = std::max<int64_t>(1, static_cast<int64_t>(value));
     else if (n == "combine_calls") h->combine_calls = value != 0;
     else if (n == "per_group_factor") h->per_group_factor = std::max<int64_t>(1, static_cast<int64_t>(value));

@@ -169,7 +169,9 @@ int gatk_pairhmm_device_count(int32_t* count);
  * of by the DMA engine, whose hand-over to the first kernel costs more than the copy of a region-sized call), and two knobs for occupancy experiments:
  * "wave_slots" (waves the planner assumes the device holds at once, default 12 per CU) and
  * "stream_lds_floor" (least bytes of LDS a wave of the fp32 stream pass asks for; a larger value
- * lowers the number of waves a CU holds), "pipeline_min_pairs" (default 12288: a compute_regions call of
+ * lowers the number of waves a CU holds), "pipeline_depth" (default 3: parts of a cut call that are in
+ * flight or being planned at once, each with buffers and a stream of its own; 2 makes the host wait for
+ * part p before it plans part p + 2), "pipeline_min_pairs" (default 12288: a compute_regions call of
  * less than two parts' worth of pairs that has the device to itself is cut in two halves of at least this
  * many pairs, so that planning the second and fetching the first hide behind kernels), and "per_group_factor" (default 32: a call, or a part of a cut
  * call, with fewer pairs than this many per wave slot uses one rows-per-lane value throughout, so that it
