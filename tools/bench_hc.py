@@ -48,7 +48,7 @@ def score(regions, device, chunk, workers, combine=False, options=()):
         for h in handles:
             h.set_option("combine_calls", 1)
     for h in handles:  # an engine in steady state: buffers grown to the largest of these calls, clocks up
-        for n, cbs, arr in (calls if workers > 1 else calls[:1]):
+        for n, cbs, arr in (calls if workers > 1 else calls[:1] * 3):
             assert lib.gatk_pairhmm_compute_regions(h._h, n, cbs, arr) == 0
     nxt = [0]
     lock = threading.Lock()
