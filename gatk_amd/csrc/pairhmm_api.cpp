@@ -215,7 +215,7 @@ struct gatk_pairhmm {
     gatk_pairhmm_resident scratch, scratch2, scratch3;
     hipStream_t stream2 = nullptr, stream3 = nullptr;
     int pipeline_depth = 3;  // parts of a cut call in flight or in planning at once (2 or 3)
-    int64_t pipeline_pairs = 131072;  // pairs per part of such a call; 0: never split a call
+    int64_t pipeline_pairs = 98304;  // pairs per part of such a call; 0: never split a call
     int64_t pipeline_min_pairs = 12288;  // the halves of a call with less than two parts' worth of pairs are at least this large
     PinnedBuf stage_in, stage_out;  // pinned staging shared by every upload / download on this handle
     hipEvent_t stage_in_copied = nullptr;  // recorded behind the host-to-device copy out of stage_in

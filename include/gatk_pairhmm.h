@@ -156,7 +156,7 @@ int gatk_pairhmm_device_count(int32_t* count);
  * "stream_mode" (1 = a wave scores a run of haplotypes back to back; 0 = one haplotype per work item;
  * -1 = automatic: runs, except in a call with fewer pairs than two per wave slot of the device, where no
  * wave would get a run and the one-haplotype pass saves a kernel launch), "max_stream_haps" (longest run, 1..16), "squash_base_quals" (1 = base qualities under 18 count as 6, see
- * gatk_pairhmm_batch), "pipeline_pairs" (default 131072: a compute call with more
+ * gatk_pairhmm_batch), "pipeline_pairs" (default 98304: a compute call with more
  * pairs is cut, between regions and inside a large region between reads, into parts of about that many pairs,
  * and one part is planned and copied while the kernels of the part before it run; 0 = never cut),
  * "pipeline_ramp" (default 1: the first two parts are a quarter and a half of that),

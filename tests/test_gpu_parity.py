@@ -528,7 +528,7 @@ def with_options_pipeline(hmm, pairs, fn):
     try:
         return fn()
     finally:
-        hmm.set_option("pipeline_pairs", 131072)
+        hmm.set_option("pipeline_pairs", 98304)
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PAIRHMM_FUZZ_SEEDS", "24"))))
@@ -555,13 +555,13 @@ def test_random_shapes_and_options(hmm, oracle, seed):
         longest = max(int(np.diff(b.read_offsets).max()) for b in regions)
         ks = [k for k in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16) if 64 * k >= longest + 2]
         opts["force_rows_per_lane"] = int(rng.choice(ks))
-    hmm.set_option("pipeline_pairs", int(rng.choice([0, 200, 131072])))
+    hmm.set_option("pipeline_pairs", int(rng.choice([0, 200, 98304])))
     try:
         got = with_options(hmm, opts, lambda: hmm.compute_regions(regions))
         hmm.set_option("fp32_threshold", 3e38)
         got64 = with_options(hmm, opts, lambda: hmm.compute_regions(regions))
     finally:
-        hmm.set_option("pipeline_pairs", 131072)
+        hmm.set_option("pipeline_pairs", 98304)
         hmm.set_option("fp32_threshold", 1e-28)
     for b, g, g64 in zip(regions, got, got64):
         want = ref(oracle, b)
