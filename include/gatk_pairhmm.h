@@ -149,34 +149,43 @@ const char* gatk_pairhmm_last_error(void);
 const char* gatk_pairhmm_version(void);
 int gatk_pairhmm_device_count(int32_t* count);
 
-/* Engine tunables (all optional).  name: "fp32_threshold" (default 1e-28: a pair whose scaled
- * fp32 sum falls below it is recomputed in fp64), "force_rows_per_lane" (0 = automatic),
- * "force_fp64" (1 = score everything in fp64), "emit_mode" (-1 = automatic, 0 = always compare bases
- * instead of using the per-wave emission table), "timing" (1 = fill the *_kernel_ms stats),
- * "stream_mode" (1 = a wave scores a run of haplotypes back to back; 0 = one haplotype per work item;
- * -1 = automatic: runs, except in a call with fewer pairs than two per wave slot of the device, where no
- * wave would get a run and the one-haplotype pass saves a kernel launch), "max_stream_haps" (longest run, 1..16), "squash_base_quals" (1 = base qualities under 18 count as 6, see
- * gatk_pairhmm_batch), "pipeline_pairs" (default 98304: a compute call with more
- * pairs is cut, between regions and inside a large region between reads, into parts of about that many pairs,
- * and one part is planned and copied while the kernels of the part before it run; 0 = never cut),
- * "pipeline_ramp" (default 1: the first two parts are a quarter and a half of that),
- * "combine_calls" (default 0; 1 = gatk_pairhmm_compute_likelihoods calls too small to fill the device, made
- * at the same time by several threads on their own handles, are scored together: a caller that finds one of
- * the device's two shared engines free takes every waiting call through one device pass, its own included,
- * the others wait for their results; same results and exceptions, per caller; only on handles whose other
- * options are the defaults, squash_base_quals aside), "kernel_upload_bytes" (default 262144: an upload of at
- * most that many bytes is copied out of the pinned staging buffer by a kernel on the compute stream instead
- * of by the DMA engine, whose hand-over to the first kernel costs more than the copy of a region-sized call), and two knobs for occupancy experiments:
- * "wave_slots" (waves the planner assumes the device holds at once, default 12 per CU) and
- * "stream_lds_floor" (least bytes of LDS a wave of the fp32 stream pass asks for; a larger value
- * lowers the number of waves a CU holds), "pipeline_depth" (default 3: parts of a cut call that are in
- * flight or being planned at once, each with buffers and a stream of its own; 2 makes the host wait for
- * part p before it plans part p + 2), "pipeline_min_pairs" (default 12288: a compute_regions call of
- * less than two parts' worth of pairs that has the device to itself is cut in two halves of at least this
- * many pairs, so that planning the second and fetching the first hide behind kernels), and "per_group_factor" (default 32: a call, or a part of a cut
- * call, with fewer pairs than this many per wave slot uses one rows-per-lane value throughout, so that it
- * costs one forward launch; a larger one chooses the value per wave-group).  Planning options take effect at the next upload or
- * host-pointer call. */
+/* Engine tunables (all optional).  Planning options take effect at the next upload or host-pointer call.
+ *   "fp32_threshold"      default 1e-28: a pair whose scaled fp32 sum falls below it is recomputed in fp64.
+ *   "force_fp64"          1 = score everything in fp64.
+ *   "force_rows_per_lane" 0 = automatic.
+ *   "emit_mode"           -1 = automatic, 0 = always compare bases instead of using the per-wave emission table.
+ *   "timing"              1 = fill the *_kernel_ms stats.
+ *   "stream_mode"         1 = a wave scores a run of haplotypes back to back; 0 = one haplotype per work item;
+ *                         -1 (default) = runs, except in a call with fewer pairs than two per wave slot of the
+ *                         device, where no wave would get a run and the one-haplotype pass saves a kernel launch.
+ *   "max_stream_haps"     longest run, 1..16.
+ *   "squash_base_quals"   1 = base qualities under 18 count as 6, see gatk_pairhmm_batch.
+ *   "pipeline_pairs"      default 98304: a compute call with more pairs is cut, between regions and inside a
+ *                         large region between reads, into parts of about that many pairs, and one part is
+ *                         planned and copied while the kernels of the parts before it run; 0 = never cut.
+ *   "pipeline_ramp"       default 1: the first two parts are a quarter and a half of that.
+ *   "pipeline_depth"      default 3: parts of a cut call that are in flight or being planned at once, each with
+ *                         buffers and a stream of its own; 2 makes the host wait for part p before it plans
+ *                         part p + 2.
+ *   "pipeline_min_pairs"  default 12288: a compute_regions call of less than two parts' worth of pairs that has
+ *                         the device to itself is cut in two halves of at least this many pairs, so that
+ *                         planning the second and fetching the first hide behind kernels.
+ *   "per_group_factor"    default 32: a call, or a part of a cut call, with fewer pairs than this many per wave
+ *                         slot uses one rows-per-lane value throughout, so that it costs one forward launch; a
+ *                         larger one chooses the value per wave-group.
+ *   "combine_calls"       default 0; 1 = gatk_pairhmm_compute_likelihoods calls too small to fill the device,
+ *                         made at the same time by several threads on their own handles, are scored together:
+ *                         a caller that finds one of the device's two shared engines free takes every waiting
+ *                         call through one device pass, its own included, the others wait for their results;
+ *                         same results and exceptions, per caller; only on handles whose other options are
+ *                         the defaults, squash_base_quals aside.
+ *   "kernel_upload_bytes" default 262144: an upload of at most that many bytes is copied out of the pinned
+ *                         staging buffer by a kernel on the compute stream instead of by the DMA engine, whose
+ *                         hand-over to the first kernel costs more than the copy of a region-sized call.
+ *   "wave_slots"          waves the planner assumes the device holds at once, default 12 per CU (occupancy
+ *                         experiments).
+ *   "stream_lds_floor"    least bytes of LDS a wave of the fp32 stream pass asks for; a larger value lowers the
+ *                         number of waves a CU holds (occupancy experiments). */
 int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value);
 
 /*
