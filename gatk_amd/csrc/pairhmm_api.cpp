@@ -210,8 +210,8 @@ struct gatk_pairhmm {
     int max_stream_haps = kMaxStreamHaps;
     bool force_fp64 = false;
     bool timing = false;
-    // buffers reused by the host-pointer entry points; two of them, each with a stream of its own, so that
-    // a call over many regions can plan and copy one part while the kernels of the part before it run
+    // buffers reused by the host-pointer entry points; three of them, each with a stream of its own, so that
+    // a call over many regions can plan and copy one part while the kernels of the two parts before it run
     gatk_pairhmm_resident scratch, scratch2, scratch3;
     hipStream_t stream2 = nullptr, stream3 = nullptr;
     int pipeline_depth = 3;  // parts of a cut call in flight or in planning at once (2 or 3)
@@ -1258,8 +1258,8 @@ int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gat
         if (int rc = enqueue_compute(h, &h->scratch)) return rc;
         return download_into(h, &h->scratch, likelihoods);
     }
-    // part p is planned and copied while the kernels of part p - 1 run; its results are fetched while the
-    // kernels of part p + 1 run
+    // part p is planned and copied while the kernels of the parts before it run; its results are fetched
+    // while the kernels of the parts behind it run
     h->scratch.stream = h->stream;
     h->scratch2.stream = h->stream2;
     h->scratch3.stream = h->stream3;
