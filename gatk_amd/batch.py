@@ -51,8 +51,10 @@ class Batch:
     def read_slice(self, lo, hi):
         """The same haplotypes with reads lo..hi-1 only (how one large batch is split over devices)."""
         a, b = int(self.read_offsets[lo]), int(self.read_offsets[hi])
-        return Batch(self.read_bases[a:b], self.read_quals[a:b], self.ins_gop[a:b], self.del_gop[a:b], self.gcp[a:b],
-                     (self.read_offsets[lo:hi + 1] - a).astype(np.int32), self.hap_bases, self.hap_offsets)
+        cut = lambda x: None if x is None else x[a:b]  # the optional arrays stay optional
+        return Batch(self.read_bases[a:b], self.read_quals[a:b], cut(self.ins_gop), cut(self.del_gop), cut(self.gcp),
+                     (self.read_offsets[lo:hi + 1] - a).astype(np.int32), self.hap_bases, self.hap_offsets,
+                     None if self.read_mapq is None else self.read_mapq[lo:hi])
 
 
 def _as_u8(x):

@@ -34,6 +34,19 @@ def test_read_slice():
     assert np.array_equal(np.diff(s.read_offsets), np.diff(b.read_offsets)[4:9])
 
 
+def test_read_slice_keeps_optional_arrays_optional_and_carries_mapq():
+    b = synth.make_batch(10, 3, 50, 120, seed=3, len_jitter=20)
+    assert b.ins_gop is not None
+    b.read_mapq = np.arange(10, dtype=np.uint8) + 20
+    s = b.read_slice(2, 7)
+    assert list(s.read_mapq) == list(range(22, 27))
+    b.ins_gop = b.del_gop = b.gcp = None
+    s = b.read_slice(2, 7)
+    assert s.ins_gop is None and s.del_gop is None and s.gcp is None and list(s.read_mapq) == list(range(22, 27))
+    b.read_mapq = None
+    assert b.read_slice(0, 3).read_mapq is None
+
+
 def test_named_configs_have_the_quoted_shapes():
     c1 = synth.config_c1()
     assert c1.num_reads == 128 and c1.num_haps == 16 and set(c1.read_lengths) == {101}
