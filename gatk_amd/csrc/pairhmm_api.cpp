@@ -46,6 +46,34 @@ hipError_t launch_upload(const void* pinned_host, void* device, size_t bytes, hi
 
 using namespace pairhmm_hip;
 
+// ---------------------------------------------------------------------------------------------
+// Working memory of gatk_pairhmm_compute_likelihoods_noalloc, the entry point for callers that cannot
+// allocate: every device holds its own copy of this array for the life of the process.  Host code never
+// uses the array's name as an address: gatk_pairhmm_create asks the runtime for the device's address once
+// (hipGetSymbolAddress) and keeps it in g_scratch_ptr[device].
+// ---------------------------------------------------------------------------------------------
+namespace noalloc {
+constexpr int kMaxReads = 4096;          // reads per call
+constexpr int kMaxHaps = 256;            // haplotypes per call
+constexpr int64_t kMaxPairs = 262144;    // reads x haplotypes per call (4096 x 64)
+constexpr int kMaxHapLen = 4096;         // haplotype_max_length a caller may declare
+constexpr size_t kHapPoolBytes = size_t{512} << 10;  // haplotypes, each padded to a multiple of 16 bytes
+constexpr size_t at_counters = 0;                                  // kCounterBytes: error word, rerun-list length
+constexpr size_t at_region_desc = 256;                             // one RegionDesc
+constexpr size_t at_read_out_base = 512;                           // int32[kMaxReads]
+constexpr size_t at_groups = at_read_out_base + kMaxReads * 4;     // GroupDesc[kMaxReads]
+constexpr size_t at_segs = at_groups + kMaxReads * 8;              // SegDesc[kMaxReads]
+constexpr size_t at_hap_off = at_segs + kMaxReads * 8;             // int32[kMaxHaps]
+constexpr size_t at_hap_len = at_hap_off + kMaxHaps * 4;           // int32[kMaxHaps]
+constexpr size_t at_hap_pool = at_hap_len + kMaxHaps * 4;          // kHapPoolBytes + 64
+constexpr size_t at_rerun_list = at_hap_pool + kHapPoolBytes + 256;  // int32[kMaxPairs]
+constexpr size_t kScratchBytes = at_rerun_list + static_cast<size_t>(kMaxPairs) * 4;  // 1.66 MB
+static_assert(sizeof(GroupDesc) == 8 && sizeof(SegDesc) == 8 && sizeof(RegionDesc) == 32, "scratch layout");
+static_assert(at_groups % 256 == 0 && at_segs % 256 == 0 && at_hap_off % 256 == 0 && at_hap_pool % 256 == 0 && at_rerun_list % 256 == 0, "scratch layout");
+}  // namespace noalloc
+
+static __device__ __align__(256) unsigned char scratch[noalloc::kScratchBytes];
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -72,6 +100,22 @@ int fail(int code, const std::string& msg) {
             return fail(e_ == hipErrorOutOfMemory ? GATK_PAIRHMM_OUT_OF_MEMORY : GATK_PAIRHMM_DEVICE_ERROR, \
                         std::string(#expr) + ": " + hipGetErrorString(e_));                             \
     } while (0)
+
+// Address of `scratch` on each device, filled once per device by setup_scratch with that device current.
+constexpr int kMaxScratchDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxScratchDevices] = {};
+
+int setup_scratch(int device) {
+    if (device < 0 || device >= kMaxScratchDevices) return GATK_PAIRHMM_OK;  // such a device has no allocation-free entry point
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return GATK_PAIRHMM_OK;
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(GATK_PAIRHMM_DEVICE_ERROR, "hipGetSymbolAddress returned no address for the scratch array");
+    g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    return GATK_PAIRHMM_OK;
+}
 
 // Grow-only device buffer.
 struct DevBuf {
@@ -1176,6 +1220,10 @@ int gatk_pairhmm_create(int device, gatk_pairhmm** out) {
         gatk_pairhmm_close(h);
         return rc;
     }
+    if (const int rc = setup_scratch(device)) {  // once per device, with the device current
+        gatk_pairhmm_close(h);
+        return rc;
+    }
     *out = h;
     return GATK_PAIRHMM_OK;
 }
@@ -1775,3 +1823,201 @@ int gatk_pairhmm_resident_device_output(gatk_pairhmm_resident* r, void** device_
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// The entry point that allocates nothing
+// =================================================================================================
+namespace {
+
+// What the device-side planner needs: the caller's offset tables and haplotype bytes (device memory), the
+// shape the host chose from the declared maxima, and where to put the descriptors.
+struct NoAllocPlan {
+    const int32_t* read_offsets;
+    const int32_t* hap_offsets;
+    const uint8_t* hap_bases;
+    int32_t num_reads, num_haps;
+    int32_t rows_per_lane;   // K of the launch
+    int32_t slot_lanes;      // lanes a read of the declared maximum length takes at that K
+    int32_t reads_per_wave;  // 64 / slot_lanes
+    int32_t read_max, hap_max;
+    unsigned char* scratch;  // this device's address of the scratch array
+    double* out;
+    int32_t* error_word;
+};
+
+// Writes, into the scratch array, what plan_and_upload lays out on the host for the one-haplotype pass: one
+// RegionDesc, a GroupDesc per wave-group, a SegDesc per read, the haplotypes on 16-byte boundaries with their
+// offsets and lengths, and -infinity for the pairs of zero-length reads.  The host cannot see the lengths
+// (they are in device memory and it may not wait), so reads go into fixed lane slots sized for the declared
+// maximum read length, reads_per_wave to a wave in read order, and every length is checked here: a read or a
+// haplotype longer than declared, an empty haplotype, decreasing offsets or more haplotype bytes than the pool
+// holds set kAbortBit in the error word, and the forward kernels behind this launch then do nothing.
+// Block 0 takes the haplotypes, the other blocks 256 reads each.
+__global__ void __launch_bounds__(256) noalloc_plan(const NoAllocPlan a) {
+    const int tid = threadIdx.x;
+    unsigned char* const S = a.scratch;
+    if (blockIdx.x == 0) {
+        __shared__ int s_off[noalloc::kMaxHaps + 1];
+        __shared__ int s_bad;
+        if (tid == 0) s_bad = 0;
+        __syncthreads();
+        for (int h = tid; h < a.num_haps; h += 256) {
+            const int len = a.hap_offsets[h + 1] - a.hap_offsets[h];
+            if (len <= 0 || len > a.hap_max) s_bad = 1;  // every writer stores the same value
+        }
+        __syncthreads();
+        if (tid == 0 && s_bad == 0) {
+            int off = 0;
+            for (int h = 0; h < a.num_haps; ++h) {
+                s_off[h] = off;
+                off += (a.hap_offsets[h + 1] - a.hap_offsets[h] + 15) & ~15;
+            }
+            s_off[a.num_haps] = off;
+            if (static_cast<size_t>(off) > noalloc::kHapPoolBytes) s_bad = 1;
+        }
+        __syncthreads();
+        if (s_bad != 0) {
+            if (tid == 0) atomicOr(a.error_word, kAbortBit);
+            return;
+        }
+        int32_t* const hap_off = reinterpret_cast<int32_t*>(S + noalloc::at_hap_off);
+        int32_t* const hap_len = reinterpret_cast<int32_t*>(S + noalloc::at_hap_len);
+        unsigned char* const pool = S + noalloc::at_hap_pool;
+        for (int h = tid; h < a.num_haps; h += 256) {
+            hap_off[h] = s_off[h];
+            hap_len[h] = a.hap_offsets[h + 1] - a.hap_offsets[h];
+        }
+        for (int h = 0; h < a.num_haps; ++h) {
+            const uint8_t* src = a.hap_bases + a.hap_offsets[h];
+            const int len = a.hap_offsets[h + 1] - a.hap_offsets[h];
+            const int padded = s_off[h + 1] - s_off[h];
+            for (int j = tid; j < padded; j += 256) pool[s_off[h] + j] = j < len ? src[j] : 0;
+        }
+        if (tid == 0) {
+            const int groups = (a.num_reads + a.reads_per_wave - 1) / a.reads_per_wave;
+            RegionDesc d{};
+            d.task_begin = 0; d.group_begin = 0; d.num_groups = groups; d.hap_begin = 0; d.num_haps = a.num_haps;
+            *reinterpret_cast<RegionDesc*>(S + noalloc::at_region_desc) = d;
+        }
+        return;
+    }
+    const int r = (blockIdx.x - 1) * 256 + tid;
+    if (r >= a.num_reads) return;
+    const int K = a.rows_per_lane;
+    const int len = a.read_offsets[r + 1] - a.read_offsets[r];
+    if (len < 0 || len > a.read_max) {
+        atomicOr(a.error_word, kAbortBit);
+        return;
+    }
+    reinterpret_cast<int32_t*>(S + noalloc::at_read_out_base)[r] = r * a.num_haps;
+    if (len == 0)  // the last matrix row is row 0: log10(0) (Log10PairHMM.java:128-134)
+        for (int h = 0; h < a.num_haps; ++h) a.out[static_cast<int64_t>(r) * a.num_haps + h] = -__builtin_inf();
+    const int slot = r % a.reads_per_wave;
+    SegDesc sd;
+    sd.read_idx = r;
+    sd.lane_begin = static_cast<uint8_t>(slot * a.slot_lanes);
+    sd.seg_lanes = static_cast<uint8_t>(len > 0 ? (len + 1 + K) / K : 0);  // no lanes for a zero-length read
+    sd.read_len = static_cast<uint16_t>(len);
+    reinterpret_cast<SegDesc*>(S + noalloc::at_segs)[r] = sd;
+    if (slot == 0) {  // the first read of a wave-group describes the group
+        const int g = r / a.reads_per_wave;
+        const int end = min(r + a.reads_per_wave, a.num_reads);
+        int max_seg = 1;
+        for (int q = r; q < end; ++q) {
+            const int l = a.read_offsets[q + 1] - a.read_offsets[q];
+            if (l > 0 && l <= a.read_max) max_seg = max(max_seg, (l + 1 + K) / K);
+        }
+        GroupDesc gd;
+        gd.seg_begin = r;
+        gd.num_segs = static_cast<int16_t>(end - r);
+        gd.fill = static_cast<int16_t>(max_seg - 1);
+        reinterpret_cast<GroupDesc*>(S + noalloc::at_groups)[g] = gd;
+    }
+}
+
+}  // namespace
+
+extern "C" int gatk_pairhmm_compute_likelihoods_noalloc(gatk_pairhmm* h, void* stream, const gatk_pairhmm_batch* device_batch,
+                                                        int32_t read_max_length, int32_t haplotype_max_length,
+                                                        double* device_likelihoods, int32_t* device_status) {
+    if (int rc = check_handle(h)) return rc;
+    const gatk_pairhmm_batch* b = device_batch;
+    if (!b) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "batch cannot be null");
+    if (b->num_reads < 0 || b->num_haps < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "negative read or haplotype count");
+    if (b->num_reads == 0 || b->num_haps == 0) return GATK_PAIRHMM_OK;  // PairHMM.java:193
+    if (b->num_reads > noalloc::kMaxReads || b->num_haps > noalloc::kMaxHaps ||
+        static_cast<int64_t>(b->num_reads) * b->num_haps > noalloc::kMaxPairs)
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "the allocation-free entry point takes at most " + std::to_string(noalloc::kMaxReads) +
+                    " reads, " + std::to_string(noalloc::kMaxHaps) + " haplotypes and " + std::to_string(noalloc::kMaxPairs) +
+                    " pairs per call, got " + std::to_string(b->num_reads) + " x " + std::to_string(b->num_haps));
+    if (read_max_length <= 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "READ_MAX_LENGTH must be > 0 but got " + std::to_string(read_max_length));
+    if (haplotype_max_length <= 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "HAPLOTYPE_MAX_LENGTH must be > 0 but got " + std::to_string(haplotype_max_length));
+    if (read_max_length > kWave * kMaxRowsPerLane - 2)
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "readBases is too long, got " + std::to_string(read_max_length) + " but max is " +
+                    std::to_string(kWave * kMaxRowsPerLane - 2));
+    if (haplotype_max_length > noalloc::kMaxHapLen)
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "Haplotype bases is too long for the allocation-free entry point, got " +
+                    std::to_string(haplotype_max_length) + " but max is " + std::to_string(noalloc::kMaxHapLen));
+    if (!b->read_bases || !b->read_quals || !b->ins_gop || !b->del_gop || !b->gcp || !b->read_offsets)
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "readBases cannot be null (the allocation-free entry point fills in no defaults)");
+    if (!b->hap_bases || !b->hap_offsets) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "haplotypeBases cannot be null");
+    if (!device_likelihoods) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "likelihoods cannot be null");
+    if (h->device < 0 || h->device >= kMaxScratchDevices || !g_scratch_ptr[h->device])
+        return fail(GATK_PAIRHMM_ILLEGAL_STATE, "no scratch array was set up for this device");
+    unsigned char* const S = g_scratch_ptr[h->device];  // the device's own copy of the array
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipSetDevice(h->device));
+
+    // shape of the launch from the declared maxima: one rows-per-lane value, reads in fixed lane slots
+    const int K = choose_group_rows_per_lane(read_max_length);
+    const int slot_lanes = (read_max_length + 1 + K) / K;
+    if (!rows_per_lane_supported(K) || slot_lanes < 1 || slot_lanes > kWave) return fail(GATK_PAIRHMM_ILLEGAL_STATE, "no rows-per-lane value for this read length");
+    const int reads_per_wave = kWave / slot_lanes;
+    const int groups = (b->num_reads + reads_per_wave - 1) / reads_per_wave;
+    const int64_t tasks = static_cast<int64_t>(groups) * b->num_haps;  // <= pairs <= kMaxPairs: the rerun list holds them all
+    const int lds = lds_bytes_per_wave(K, kEmitCompareN, haplotype_max_length);
+    if (tasks > noalloc::kMaxPairs || lds * kWavesPerBlock > 64 * 1024) return fail(GATK_PAIRHMM_ILLEGAL_STATE, "launch shape outside the scratch array");
+
+    int32_t* const counters = reinterpret_cast<int32_t*>(S + noalloc::at_counters);
+    int32_t* const error_word = device_status ? device_status : counters;
+    // the array keeps the last call's contents: the counters must start at zero (descriptors are rewritten)
+    HIP_TRY(hipMemsetAsync(counters, 0, kCounterBytes, s));
+    if (device_status) HIP_TRY(hipMemsetAsync(device_status, 0, sizeof(int32_t), s));
+
+    NoAllocPlan plan{b->read_offsets, b->hap_offsets, b->hap_bases, b->num_reads, b->num_haps, K, slot_lanes, reads_per_wave,
+                     read_max_length, haplotype_max_length, S, device_likelihoods, error_word};
+    hipLaunchKernelGGL(noalloc_plan, dim3(1 + (b->num_reads + 255) / 256), dim3(256), 0, s, plan);
+    HIP_TRY(hipGetLastError());
+
+    DeviceBatch B{};
+    B.read_bases = b->read_bases; B.read_quals = b->read_quals; B.ins_gop = b->ins_gop; B.del_gop = b->del_gop; B.gcp = b->gcp;
+    B.read_mapq = b->read_mapq;
+    B.squash_base_quals = h->squash_base_quals ? 1 : 0;
+    B.read_off = b->read_offsets;
+    B.read_out_base = reinterpret_cast<const int32_t*>(S + noalloc::at_read_out_base);
+    B.hap_pool = S + noalloc::at_hap_pool;
+    B.hap_off = reinterpret_cast<const int32_t*>(S + noalloc::at_hap_off);
+    B.hap_len = reinterpret_cast<const int32_t*>(S + noalloc::at_hap_len);
+    B.groups = reinterpret_cast<const GroupDesc*>(S + noalloc::at_groups);
+    B.segs = reinterpret_cast<const SegDesc*>(S + noalloc::at_segs);
+    B.region_descs = reinterpret_cast<const RegionDesc*>(S + noalloc::at_region_desc);
+    B.row_consts = nullptr;  // the forward kernel works the row constants out itself, quality checks included
+    B.num_reads = b->num_reads;
+    B.num_haps = b->num_haps;
+    B.num_region_descs = 1;
+    B.num_tasks = static_cast<int32_t>(tasks);
+    B.err_prob = h->d_err;
+    B.match_to_match = h->d_mm;
+    B.out = device_likelihoods;
+    B.rerun_count = counters + 1;
+    B.rerun_list = reinterpret_cast<int32_t*>(S + noalloc::at_rerun_list);
+    B.error_word = error_word;
+    B.abort_word = error_word;
+    B.fp32_threshold = h->fp32_threshold;
+    B.lds_per_wave = lds;
+    const int blocks = static_cast<int>((tasks + kWavesPerBlock - 1) / kWavesPerBlock);
+    HIP_TRY(launch_forward(B, K, kEmitCompareN, false, false, blocks, s));
+    HIP_TRY(launch_forward(B, K, kEmitCompareN, true, true, std::min(blocks, 1024), s));
+    return GATK_PAIRHMM_OK;
+}
+

@@ -161,6 +161,11 @@ struct DeviceBatch {
     int64_t total_read_bytes;
     const int32_t* neg_inf_idx;    // [num_neg_inf] indices in out[] of the pairs of zero-length reads
     int32_t num_neg_inf;
+    // Set only by passes whose descriptors are written on the device: the one-haplotype kernels leave at once
+    // when bit kAbortBit of this word is set (the descriptors are then not to be trusted).  Null otherwise.
+    const int32_t* abort_word;
 };
+
+constexpr int32_t kAbortBit = 4;  // error-word bit: a length exceeds what the caller declared, nothing was scored
 
 }  // namespace pairhmm_hip

@@ -1043,6 +1043,7 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_direct(const Device
     const int lane = threadIdx.x & (kWave - 1);
     const int task = blockIdx.x * kWavesPerBlock + wave;
     if (task >= B.num_tasks) return;
+    if (B.abort_word != nullptr && (*B.abort_word & kAbortBit) != 0) return;
     run_task<T, K, MODE>(B, task, lds + wave * B.lds_per_wave, lane, std::is_same<T, float>::value);
 }
 
@@ -1053,6 +1054,7 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_list(const DeviceBa
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & (kWave - 1);
+    if (B.abort_word != nullptr && (*B.abort_word & kAbortBit) != 0) return;
     int n = *B.rerun_count;
     if (n > B.num_tasks) n = B.num_tasks;
     const int stride = gridDim.x * kWavesPerBlock;

@@ -71,7 +71,7 @@ EXPORTS = [
     "gatk_pairhmm_set_option", "gatk_pairhmm_upload", "gatk_pairhmm_compute_resident", "gatk_pairhmm_download",
     "gatk_pairhmm_resident_free", "gatk_pairhmm_get_stream", "gatk_pairhmm_resident_device_output",
     "gatk_pairhmm_wait_resident", "gatk_pairhmm_normalize_resident", "gatk_pairhmm_poorly_modeled_resident",
-    "gatk_pairhmm_marginalize_resident",
+    "gatk_pairhmm_marginalize_resident", "gatk_pairhmm_compute_likelihoods_noalloc",
 ]
 
 _lib = None
@@ -113,6 +113,8 @@ def load_library():
         L.gatk_pairhmm_compute_likelihoods_ptrs.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 9
         L.gatk_pairhmm_batch_add.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.gatk_pairhmm_compute_likelihoods_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CBatch), C.c_int32, C.c_int32,
+                                                               C.c_void_p, C.c_void_p]
         L.gatk_pairhmm_device_count.argtypes = [C.POINTER(C.c_int32)]
         L.gatk_pairhmm_set_number_of_threads.argtypes = [C.c_int32]
         _lib = L
@@ -269,6 +271,12 @@ class HipLoglessPairHMM:
         arr = (C.c_void_p * max(1, len(regions)))(*[o.ctypes.data if o.size else None for o in outs])
         _check(self._lib.gatk_pairhmm_compute_regions(self._h, len(regions), cbs, arr))
         return outs
+
+    def compute_device_batch_noalloc(self, cbatch: CBatch, read_max_length, haplotype_max_length, out_ptr, status_ptr=None, stream=None):
+        """gatk_pairhmm_compute_likelihoods_noalloc: `cbatch` holds DEVICE pointers, out_ptr / status_ptr are device
+        addresses, stream a hipStream_t address (None: the default stream).  Enqueues and returns; allocates nothing."""
+        _check(self._lib.gatk_pairhmm_compute_likelihoods_noalloc(self._h, stream, C.byref(cbatch), read_max_length,
+                                                                  haplotype_max_length, out_ptr, status_ptr))
 
     def upload(self, regions) -> Resident:
         keep = []

@@ -229,6 +229,37 @@ int gatk_pairhmm_poorly_modeled_resident(gatk_pairhmm* h, gatk_pairhmm_resident*
 int gatk_pairhmm_marginalize_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, const int32_t* const* old_to_new_allele_index,
                                       const int32_t* new_allele_count, double* const* new_likelihoods);
 
+/*
+ * gatk_pairhmm_compute_likelihoods for callers that cannot allocate.  No counterpart in the reference: it is for
+ * callers that may not call hipMalloc or wait on the device - code under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation.  One computeLikelihoods call (one region) whose inputs and outputs are already
+ * in device memory: every pointer of device_batch, device_likelihoods and device_status is a DEVICE pointer on the
+ * handle's GPU (read_mapq may be NULL; ins_gop, del_gop and gcp may not: no defaults are filled in here).  The
+ * call enqueues its kernels on `stream` (a hipStream_t; NULL = the default stream) and returns without waiting;
+ * likelihoods[r * num_haps + a] is complete once the stream has passed them.  It calls no hipMalloc, hipFree or
+ * other allocating routine: descriptors, the haplotype copy and the fp64 rerun list live in a fixed 1.7 MB
+ * array in each GPU's memory that the library holds from load to exit.
+ *
+ * The host cannot see lengths that live in device memory, so the caller declares them: no read is longer than
+ * read_max_length (<= 1022), no haplotype longer than haplotype_max_length (<= 4096).  Limits per call:
+ * 4096 reads, 256 haplotypes, 262144 pairs, 512 KiB of haplotype bases (each haplotype rounded up to 16);
+ * a call beyond them fails with ILLEGAL_ARGUMENT before anything is enqueued.
+ *
+ * Errors that only the device can see come back in *device_status (may be NULL: then they are lost), valid
+ * once the stream has passed the call: bit 0 = negative insertion / deletion / GCP byte
+ * (IllegalArgumentException, PairHMMModel.java:136-138), bit 1 = base quality 255
+ * (ArrayIndexOutOfBoundsException, QualityUtils.java:173), bit 2 = a length contradicts the declared maxima,
+ * an empty haplotype, decreasing offsets or too many haplotype bytes: nothing was scored and the likelihoods
+ * are unspecified.
+ *
+ * Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two streams, two threads) race.
+ * Calls on one stream, or otherwise ordered one after the other, are safe.  Handle options honoured:
+ * fp32_threshold, squash_base_quals.
+ */
+int gatk_pairhmm_compute_likelihoods_noalloc(gatk_pairhmm* h, void* stream, const gatk_pairhmm_batch* device_batch,
+                                             int32_t read_max_length, int32_t haplotype_max_length,
+                                             double* device_likelihoods, int32_t* device_status);
+
 /* Device pointer to the resident likelihood array (all regions concatenated, region-major). */
 int gatk_pairhmm_resident_device_output(gatk_pairhmm_resident* r, void** device_ptr, int64_t* count);
 
