@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <cstdio>
 #include <cstring>
@@ -78,9 +79,11 @@ namespace {
 
 thread_local std::string g_last_error;
 std::atomic<int> g_num_threads{1};
+std::atomic<int> g_live_handles{0};  // callers' single-device handles (the combiner's shared engines are not counted)
+void release_shared_engines_if_last();
 // compute_regions calls under way per device (all handles): a call that has the device to itself overlaps
 // its own halves; one that shares it is overlapped with the calls of the other handles already
-std::atomic<int> g_region_calls[64];
+std::atomic<int> g_region_calls[64];  // indexed by device & 63: devices 64 apart would share a count, which only costs overlap
 struct RegionCallCount {
     std::atomic<int>& n;
     int others;
@@ -233,7 +236,54 @@ struct gatk_pairhmm_resident {
     }
 };
 
+// One host thread of a multi-device handle: runs the jobs it is given one at a time on its own device's engine.
+struct DeviceWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = true, stop = false;
+    void start() { th = std::thread([this] { loop(); }); }
+    void loop() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return has_job || stop; });
+            if (!has_job) return;  // stop
+            std::function<void()> j = std::move(job);
+            has_job = false;
+            lk.unlock();
+            j();
+            lk.lock();
+            done = true;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<void()> j) {
+        { std::lock_guard<std::mutex> lk(m); job = std::move(j); has_job = true; done = false; }
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return done; });
+    }
+    void shutdown() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+
 struct gatk_pairhmm {
+    // A multi-device handle (gatk_pairhmm_create_multi) owns one single-device engine per entry of its device
+    // list and computes nothing itself: its compute calls shard regions over the engines.  children[0] runs on
+    // the calling thread, children[k > 0] on workers[k - 1].
+    std::vector<gatk_pairhmm*> children;
+    std::vector<std::unique_ptr<DeviceWorker>> workers;
+    unsigned next_child = 0;     // small calls go to the engines in turn
+    bool stats_in_first_engine = false;  // the last call went through the resident interface, which the first engine serves
+    int64_t multi_min_pairs = 8192;  // a call with fewer pairs goes to one engine on the calling thread
+    bool is_shared_engine = false;  // an engine of the call combiner, not a caller's handle
+    bool counted = false;           // counted among the live callers' handles (see release_shared_engines_if_last)
     int device = 0;
     hipStream_t stream = nullptr;
     int wave_slots = 3072;  // waves the device holds at once at three per SIMD
@@ -377,7 +427,7 @@ int choose_group_rows_per_lane(int longest) {
     return table[longest];
 }
 
-int check_region(const gatk_pairhmm_batch& b, int k) {
+int check_region(const gatk_pairhmm_batch& b, int k, int* read_max_out = nullptr, int* hap_max_out = nullptr) {
     const auto where = [k] { return " (region " + std::to_string(k) + ")"; };  // built only for a failure
     if (b.num_reads < 0 || b.num_haps < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("negative read or haplotype count") + where());
     if (b.num_reads == 0) return GATK_PAIRHMM_OK;  // PairHMM.java:193
@@ -408,7 +458,20 @@ int check_region(const gatk_pairhmm_batch& b, int k) {
     if (hap_max > kMaxHapLen)
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "Haplotype bases is too long, got " + std::to_string(hap_max) + " but max is " +
                                                        std::to_string(kMaxHapLen) + where());
+    if (read_max_out) *read_max_out = read_max;
+    if (hap_max_out) *hap_max_out = hap_max;
     return GATK_PAIRHMM_OK;
+}
+
+// PairHMM.java:198-201: a computeLikelihoods call whose longest read or longest haplotype exceeds the instance's
+// maxima (or the first call) re-initialises the instance with THIS call's two maxima, so the other one may shrink.
+void note_call_maxima(gatk_pairhmm* h, const gatk_pairhmm_batch& b, int read_max, int hap_max) {
+    if (b.num_reads == 0 || b.num_haps == 0) return;
+    if (!h->initialized || read_max > h->max_read || hap_max > h->max_hap) {
+        h->max_read = read_max;
+        h->max_hap = hap_max;
+        h->initialized = true;
+    }
 }
 
 // Carves aligned sub-arrays out of one staging buffer; the same offsets are valid in the device arena.
@@ -504,8 +567,11 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     const double t_begin = now_ms();
     if (num_regions < 0 || (num_regions > 0 && !regions)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "regions cannot be null");
     if (!checked)
-        for (int k = 0; k < num_regions; ++k)
-            if (int rc = check_region(regions[k], k)) return rc;
+        for (int k = 0; k < num_regions; ++k) {
+            int read_max = 0, hap_max = 0;
+            if (int rc = check_region(regions[k], k, &read_max, &hap_max)) return rc;
+            note_call_maxima(h, regions[k], read_max, hap_max);
+        }
 
     R->num_regions = num_regions;
     R->region_out_off.assign(num_regions + 1, 0);
@@ -566,7 +632,6 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     std::vector<StreamDesc> stream_descs;
     bool any_hap_n = false, any_hap_other = false;
     int64_t cells = 0;
-    int read_max_all = 0, hap_max_all = 0;
     int read_cursor = 0, hap_cursor = 0;
     for (int k = 0; k < num_regions; ++k) {
         const gatk_pairhmm_batch& b = regions[k];
@@ -582,7 +647,6 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             rp.hap_max = std::max(rp.hap_max, len);
             if (!any_hap_other) scan_alphabet(b.hap_bases + o, len, any_hap_n, any_hap_other);
         }
-        hap_max_all = std::max(hap_max_all, rp.hap_max);
         int read_max = 0, read_min = std::numeric_limits<int>::max(), nonempty = 0;
         int64_t len_total = 0;
         for (int r = 0; r < nr; ++r) {
@@ -599,7 +663,6 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             }
         }
         cells += len_total * hap_total;
-        read_max_all = std::max(read_max_all, read_max);
         rp.read_max = read_max;
         // wave-groups: longest reads first (equal lengths in read order), filled lane segment by lane segment
         // up to 64 lanes.  Lengths are small integers: a counting sort.
@@ -660,13 +723,6 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         }
         read_cursor += nr;
         hap_cursor += nh;
-    }
-
-    // PairHMM.java:200-201: grow the instance's maxima when a batch exceeds them
-    if (call_pairs > 0 && (!h->initialized || read_max_all > h->max_read || hap_max_all > h->max_hap)) {
-        h->max_read = std::max(h->max_read, read_max_all);
-        h->max_hap = std::max(h->max_hap, hap_max_all);
-        h->initialized = true;
     }
 
     // ---- buckets: one launch per rows-per-lane value; longest work items first -----------------
@@ -1171,6 +1227,16 @@ int check_handle(gatk_pairhmm* h) {
     return GATK_PAIRHMM_OK;
 }
 
+// The resident interface, the allocation-free entry point and the stream getter work on one device: on a
+// multi-device handle they are served by the engine of the first device in the handle's list.
+gatk_pairhmm* first_engine(gatk_pairhmm* h) {
+    if (h && !h->children.empty()) {
+        h->stats_in_first_engine = true;
+        return h->children[0];
+    }
+    return h;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1201,6 +1267,13 @@ int gatk_pairhmm_create(int device, gatk_pairhmm** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(GATK_PAIRHMM_DEVICE_ERROR, "no HIP device is visible: the PairHMM engine has no CPU fallback");
     if (device < 0 || device >= n) return fail(GATK_PAIRHMM_DEVICE_ERROR, "device index out of range");
+    {   // the library holds gfx950 code only: say so here rather than at the first launch
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(GATK_PAIRHMM_DEVICE_ERROR, "device " + std::to_string(device) + " is " + prop.gcnArchName +
+                        ": the PairHMM engine is built for gfx950 (MI355X) only");
+    }
     HIP_TRY(hipSetDevice(device));
     gatk_pairhmm* h = new gatk_pairhmm();
     h->device = device;
@@ -1224,6 +1297,8 @@ int gatk_pairhmm_create(int device, gatk_pairhmm** out) {
         gatk_pairhmm_close(h);
         return rc;
     }
+    h->counted = true;
+    g_live_handles.fetch_add(1);
     *out = h;
     return GATK_PAIRHMM_OK;
 }
@@ -1235,15 +1310,21 @@ int gatk_pairhmm_initialize(gatk_pairhmm* h, int32_t read_max_length, int32_t ha
     h->max_read = read_max_length;
     h->max_hap = haplotype_max_length;
     h->initialized = true;
+    for (gatk_pairhmm* c : h->children) { c->max_read = read_max_length; c->max_hap = haplotype_max_length; c->initialized = true; }
     return GATK_PAIRHMM_OK;
 }
 
-int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
-                                 double* const* likelihoods) {
-    if (int rc = check_handle(h)) return rc;
-    if (num_regions < 0 || (num_regions > 0 && !regions)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "regions cannot be null");
-    for (int k = 0; k < num_regions; ++k)
-        if (int rc = check_region(regions[k], k)) return rc;
+static int compute_regions_multi(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions, double* const* likelihoods);
+
+// compute_regions on a single-device handle.  checked: the caller has run check_region on every region already.
+static int compute_regions_single(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
+                                  double* const* likelihoods, bool checked) {
+    if (!checked)
+        for (int k = 0; k < num_regions; ++k) {
+            int read_max = 0, hap_max = 0;
+            if (int rc = check_region(regions[k], k, &read_max, &hap_max)) return rc;
+            note_call_maxima(h, regions[k], read_max, hap_max);
+        }
     const RegionCallCount in_flight(h->device);
     // A region with more pairs than a part holds is cut by read ranges (its pairs are independent,
     // PairHMM.java:217): the pieces share its haplotypes and write into consecutive rows of its array.
@@ -1357,6 +1438,148 @@ int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gat
     return GATK_PAIRHMM_OK;
 }
 
+int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
+                                 double* const* likelihoods) {
+    if (int rc = check_handle(h)) return rc;
+    if (num_regions < 0 || (num_regions > 0 && !regions)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "regions cannot be null");
+    if (!h->children.empty()) return compute_regions_multi(h, num_regions, regions, likelihoods);
+    return compute_regions_single(h, num_regions, regions, likelihoods, false);
+}
+
+int gatk_pairhmm_create_multi(const int32_t* devices, int32_t num_devices, gatk_pairhmm** out) {
+    if (!out) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "out cannot be null");
+    *out = nullptr;
+    std::vector<int> list;
+    if (!devices || num_devices <= 0) {  // every visible device
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+            return fail(GATK_PAIRHMM_DEVICE_ERROR, "no HIP device is visible: the PairHMM engine has no CPU fallback");
+        for (int d = 0; d < n; ++d) list.push_back(d);
+    } else {
+        list.assign(devices, devices + num_devices);
+    }
+    gatk_pairhmm* h = new gatk_pairhmm();
+    h->device = list[0];
+    for (int d : list) {
+        gatk_pairhmm* child = nullptr;
+        if (const int rc = gatk_pairhmm_create(d, &child)) {
+            const std::string msg = g_last_error;
+            gatk_pairhmm_close(h);
+            return fail(rc, msg);
+        }
+        h->children.push_back(child);
+    }
+    for (size_t k = 1; k < h->children.size(); ++k) {
+        h->workers.emplace_back(new DeviceWorker());
+        h->workers.back()->start();
+    }
+    *out = h;
+    return GATK_PAIRHMM_OK;
+}
+
+// compute_regions on a multi-device handle: the regions go to the engines longest-processing-time first by cell
+// count (sum of readLen * hapLen), a region worth more than half a device's share is cut by read ranges first
+// (its pairs are independent, PairHMM.java:217), every engine plans, copies and scores its share on a host
+// thread of its own with its own overlapped pipeline, and writes into the caller's likelihoods[k] directly:
+// no gather copy, nothing between devices.
+static int compute_regions_multi(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions, double* const* likelihoods) {
+    const int n_dev = static_cast<int>(h->children.size());
+    std::vector<int64_t> cells(static_cast<size_t>(num_regions), 0);
+    int64_t total_cells = 0, total_pairs = 0;
+    for (int k = 0; k < num_regions; ++k) {
+        int read_max = 0, hap_max = 0;
+        if (int rc = check_region(regions[k], k, &read_max, &hap_max)) return rc;
+        note_call_maxima(h, regions[k], read_max, hap_max);
+        const gatk_pairhmm_batch& b = regions[k];
+        if (b.num_reads == 0 || b.num_haps == 0) continue;
+        if (!likelihoods || !likelihoods[k]) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "likelihoods cannot be null");
+        cells[k] = static_cast<int64_t>(b.read_offsets[b.num_reads] - b.read_offsets[0]) * (b.hap_offsets[b.num_haps] - b.hap_offsets[0]);
+        total_cells += cells[k];
+        total_pairs += static_cast<int64_t>(b.num_reads) * b.num_haps;
+    }
+    for (gatk_pairhmm* c : h->children) { c->initialized = h->initialized; c->max_read = h->max_read; c->max_hap = h->max_hap; }
+    h->stats_in_first_engine = false;
+    if (total_pairs == 0) { h->stats = gatk_pairhmm_stats{}; return GATK_PAIRHMM_OK; }
+    if (n_dev == 1 || total_pairs < h->multi_min_pairs) {  // not worth a hand-over between threads
+        gatk_pairhmm* c = h->children[h->next_child++ % n_dev];
+        const int rc = compute_regions_single(c, num_regions, regions, likelihoods, true);
+        h->stats = c->stats;
+        return rc;
+    }
+    // pieces: whole regions, or read ranges of a region worth more than half a device's share
+    struct Piece { gatk_pairhmm_batch b; double* out; int64_t cells; };
+    std::vector<Piece> pieces;
+    pieces.reserve(static_cast<size_t>(num_regions) + 4 * n_dev);
+    const int64_t share = std::max<int64_t>(total_cells / n_dev, 1);
+    for (int k = 0; k < num_regions; ++k) {
+        const gatk_pairhmm_batch& b = regions[k];
+        if (cells[k] == 0) continue;
+        int n_pieces = 1;
+        if (2 * cells[k] > share) n_pieces = static_cast<int>(std::min<int64_t>((4 * cells[k] + share - 1) / share, b.num_reads));
+        for (int q = 0; q < n_pieces; ++q) {
+            const int r0 = static_cast<int>(static_cast<int64_t>(b.num_reads) * q / n_pieces);
+            const int r1 = static_cast<int>(static_cast<int64_t>(b.num_reads) * (q + 1) / n_pieces);
+            if (r1 == r0) continue;
+            Piece pc{b, likelihoods[k] + static_cast<int64_t>(r0) * b.num_haps, 0};
+            pc.b.num_reads = r1 - r0;
+            pc.b.read_offsets = b.read_offsets + r0;  // offsets stay absolute
+            if (b.read_mapq) pc.b.read_mapq = b.read_mapq + r0;
+            pc.cells = static_cast<int64_t>(b.read_offsets[r1] - b.read_offsets[r0]) * (b.hap_offsets[b.num_haps] - b.hap_offsets[0]);
+            pieces.push_back(pc);
+        }
+    }
+    // longest processing time first; ties in input order, so the assignment is deterministic
+    std::vector<int> order(pieces.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pieces[a].cells > pieces[b].cells; });
+    std::vector<std::vector<int>> mine(static_cast<size_t>(n_dev));
+    std::vector<int64_t> load(static_cast<size_t>(n_dev), 0);
+    for (int i : order) {
+        int best = 0;
+        for (int d = 1; d < n_dev; ++d)
+            if (load[d] < load[best]) best = d;
+        mine[best].push_back(i);
+        load[best] += pieces[i].cells;
+    }
+    struct Share {
+        std::vector<gatk_pairhmm_batch> batches;
+        std::vector<double*> outs;
+        int rc = GATK_PAIRHMM_OK;
+        std::string error;
+    };
+    std::vector<Share> shares(static_cast<size_t>(n_dev));
+    for (int d = 0; d < n_dev; ++d) {
+        std::sort(mine[d].begin(), mine[d].end());  // input order within a device: neighbouring read ranges stay neighbours
+        for (int i : mine[d]) { shares[d].batches.push_back(pieces[i].b); shares[d].outs.push_back(pieces[i].out); }
+    }
+    auto run = [&](int d) {
+        Share& sh = shares[d];
+        if (sh.batches.empty()) { h->children[d]->stats = gatk_pairhmm_stats{}; return; }
+        sh.rc = compute_regions_single(h->children[d], static_cast<int32_t>(sh.batches.size()), sh.batches.data(), sh.outs.data(), true);
+        if (sh.rc != GATK_PAIRHMM_OK) sh.error = g_last_error;  // this thread's message
+    };
+    for (int d = 1; d < n_dev; ++d) h->workers[d - 1]->submit([&run, d] { run(d); });
+    run(0);
+    for (int d = 1; d < n_dev; ++d) h->workers[d - 1]->wait();
+    gatk_pairhmm_stats total{};
+    for (int d = 0; d < n_dev; ++d) {  // counts add up; times are the slowest device's
+        const gatk_pairhmm_stats& st = h->children[d]->stats;
+        total.pairs += st.pairs; total.cells += st.cells; total.wave_tasks += st.wave_tasks;
+        total.rerun_tasks += st.rerun_tasks; total.rerun_pairs += st.rerun_pairs;
+        total.fp32_kernel_ms = std::max(total.fp32_kernel_ms, st.fp32_kernel_ms);
+        total.fp64_kernel_ms = std::max(total.fp64_kernel_ms, st.fp64_kernel_ms);
+        total.aux_kernel_ms = std::max(total.aux_kernel_ms, st.aux_kernel_ms);
+        total.host_plan_ms = std::max(total.host_plan_ms, st.host_plan_ms);
+        total.host_upload_ms = std::max(total.host_upload_ms, st.host_upload_ms);
+        total.timed_passes = std::max(total.timed_passes, st.timed_passes);
+    }
+    h->stats = total;
+    for (int d = 0; d < n_dev; ++d)
+        if (shares[d].rc != GATK_PAIRHMM_OK)
+            return fail(shares[d].rc, shares[d].error + " (device " + std::to_string(h->children[d]->device) + ")");
+    return GATK_PAIRHMM_OK;
+}
+
 namespace {
 
 // Region-sized calls from several threads, each on its own handle (the reference's one PairHMM per map
@@ -1391,6 +1614,22 @@ Combiner* combiner_for(int device, bool squash) {
     Combiner*& c = g_combiners[device * 2 + (squash ? 1 : 0)];
     if (!c) c = new Combiner();
     return c;
+}
+
+// The shared engines and their device buffers go when the last caller's handle on the process closes (no call can
+// be under way then: a call needs a handle); the next combined call creates them again.
+void release_shared_engines_if_last() {
+    if (g_live_handles.fetch_sub(1) != 1) return;
+    std::lock_guard<std::mutex> lock(g_combiners_mutex);
+    for (auto& kv : g_combiners) {
+        Combiner* c = kv.second;
+        std::lock_guard<std::mutex> inner(c->m);
+        for (int e = 0; e < Combiner::kEngines; ++e)
+            if (c->engine[e] && !c->busy[e]) {
+                gatk_pairhmm_close(c->engine[e]);
+                c->engine[e] = nullptr;
+            }
+    }
 }
 
 // One pass over the requests a leader took.  A failing pass is repeated request by request so that the
@@ -1430,7 +1669,12 @@ int compute_combined(int device, bool squash, const gatk_pairhmm_batch* batch, d
         lock.unlock();
         if (!c->engine[e]) {  // only the thread that holds busy[e] touches engine[e]
             create_rc = gatk_pairhmm_create(device, &c->engine[e]);
-            if (create_rc == GATK_PAIRHMM_OK) c->engine[e]->squash_base_quals = squash;
+            if (create_rc == GATK_PAIRHMM_OK) {
+                c->engine[e]->squash_base_quals = squash;
+                c->engine[e]->is_shared_engine = true;  // not a caller's handle
+                c->engine[e]->counted = false;
+                g_live_handles.fetch_sub(1);
+            }
             else create_error = g_last_error;
         }
         if (create_rc == GATK_PAIRHMM_OK) run_combined(c->engine[e], reqs);
@@ -1458,18 +1702,13 @@ int gatk_pairhmm_compute_likelihoods(gatk_pairhmm* h, const gatk_pairhmm_batch* 
     // combined: a call that cannot fill the device by itself, on a handle whose other options are the defaults
     const bool plain = h->fp32_threshold == 1e-28f && h->force_rows_per_lane == 0 && !h->force_fp64 && h->emit_mode == -1 &&
                        h->stream_mode == -1 && !h->timing;
-    if (h->combine_calls && plain && n < 4 * static_cast<int64_t>(h->wave_slots)) {
-        if (int rc = check_region(*batch, 0)) return rc;
+    if (h->combine_calls && h->children.empty() && plain && n < 4 * static_cast<int64_t>(h->wave_slots)) {
+        int read_max = 0, hap_max = 0;
+        if (int rc = check_region(*batch, 0, &read_max, &hap_max)) return rc;
         if (int rc = compute_combined(h->device, h->squash_base_quals, batch, likelihoods)) return rc;
         h->stats = gatk_pairhmm_stats{};
         h->stats.pairs = n;
-        // PairHMM.java:200-201: this instance's maxima grow with the batches it has seen
-        int read_max = 0, hap_max = 0;
-        for (int r = 0; r < batch->num_reads; ++r) read_max = std::max(read_max, batch->read_offsets[r + 1] - batch->read_offsets[r]);
-        for (int a = 0; a < batch->num_haps; ++a) hap_max = std::max(hap_max, batch->hap_offsets[a + 1] - batch->hap_offsets[a]);
-        h->max_read = std::max(h->max_read, read_max);
-        h->max_hap = std::max(h->max_hap, hap_max);
-        h->initialized = true;
+        note_call_maxima(h, *batch, read_max, hap_max);
     } else if (int rc = gatk_pairhmm_compute_regions(h, 1, batch, outs)) return rc;
     h->likelihood_array.assign(likelihoods, likelihoods + n);  // mLikelihoodArray, PairHMM.java:206,225
     return GATK_PAIRHMM_OK;
@@ -1599,6 +1838,13 @@ int gatk_pairhmm_finalize_region(gatk_pairhmm* h) {
 
 int gatk_pairhmm_close(gatk_pairhmm* h) {
     if (!h) return GATK_PAIRHMM_OK;
+    if (!h->children.empty() || !h->workers.empty()) {  // a multi-device handle owns engines and threads only
+        for (auto& w : h->workers) w->shutdown();
+        for (gatk_pairhmm* c : h->children) gatk_pairhmm_close(c);
+        delete h;
+        return GATK_PAIRHMM_OK;
+    }
+    if (h->counted) release_shared_engines_if_last();
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
@@ -1621,7 +1867,7 @@ int gatk_pairhmm_close(gatk_pairhmm* h) {
 int gatk_pairhmm_get_stats(gatk_pairhmm* h, gatk_pairhmm_stats* out) {
     if (int rc = check_handle(h)) return rc;
     if (!out) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "out cannot be null");
-    *out = h->stats;
+    *out = (!h->children.empty() && h->stats_in_first_engine) ? h->children[0]->stats : h->stats;
     return GATK_PAIRHMM_OK;
 }
 
@@ -1629,7 +1875,11 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
     if (int rc = check_handle(h)) return rc;
     if (!name) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "name cannot be null");
     const std::string n(name);
-    if (n == "fp32_threshold") h->fp32_threshold = static_cast<float>(value);
+    for (gatk_pairhmm* c : h->children)
+        if (n != "multi_min_pairs")
+            if (int rc = gatk_pairhmm_set_option(c, name, value)) return rc;
+    if (n == "multi_min_pairs") h->multi_min_pairs = std::max<int64_t>(0, static_cast<int64_t>(value));
+    else if (n == "fp32_threshold") h->fp32_threshold = static_cast<float>(value);
     else if (n == "force_rows_per_lane") h->force_rows_per_lane = static_cast<int>(value);
     else if (n == "force_fp64") h->force_fp64 = value != 0;
     else if (n == "emit_mode") h->emit_mode = static_cast<int>(value);
@@ -1653,6 +1903,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
 int gatk_pairhmm_upload(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
                         gatk_pairhmm_resident** out) {
     if (int rc = check_handle(h)) return rc;
+    h = first_engine(h);
     if (!out) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "out cannot be null");
     *out = nullptr;
     auto* R = new gatk_pairhmm_resident();
@@ -1667,6 +1918,7 @@ int gatk_pairhmm_upload(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm
 
 int gatk_pairhmm_compute_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, int32_t sync) {
     if (int rc = check_handle(h)) return rc;
+    h = first_engine(h);
     if (!r) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "resident batch cannot be null");
     if (r->total_pairs > 0)
         if (int rc = enqueue_compute(h, r)) return rc;
@@ -1676,6 +1928,7 @@ int gatk_pairhmm_compute_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, int
 
 int gatk_pairhmm_wait_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r) {
     if (int rc = check_handle(h)) return rc;
+    h = first_engine(h);
     if (!r) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "resident batch cannot be null");
     if (r->total_pairs == 0) return GATK_PAIRHMM_OK;
     if (!r->computed) return fail(GATK_PAIRHMM_ILLEGAL_STATE, "wait before compute_resident");
@@ -1684,6 +1937,7 @@ int gatk_pairhmm_wait_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r) {
 
 int gatk_pairhmm_download(gatk_pairhmm* h, gatk_pairhmm_resident* r, double* const* likelihoods) {
     if (int rc = check_handle(h)) return rc;
+    h = first_engine(h);
     if (!r) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "resident batch cannot be null");
     if (r->total_pairs > 0 && !r->computed) return fail(GATK_PAIRHMM_ILLEGAL_STATE, "download before compute_resident");
     return download_into(h, r, likelihoods);
@@ -1691,6 +1945,7 @@ int gatk_pairhmm_download(gatk_pairhmm* h, gatk_pairhmm_resident* r, double* con
 
 int gatk_pairhmm_resident_free(gatk_pairhmm* h, gatk_pairhmm_resident* r) {
     if (int rc = check_handle(h)) return rc;
+    h = first_engine(h);
     if (!r) return GATK_PAIRHMM_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
@@ -1701,6 +1956,7 @@ int gatk_pairhmm_resident_free(gatk_pairhmm* h, gatk_pairhmm_resident* r) {
 
 int gatk_pairhmm_get_stream(gatk_pairhmm* h, void** stream) {
     if (int rc = check_handle(h)) return rc;
+    h = first_engine(h);
     if (!stream) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "stream cannot be null");
     *stream = h->stream;
     return GATK_PAIRHMM_OK;
@@ -1709,8 +1965,9 @@ int gatk_pairhmm_get_stream(gatk_pairhmm* h, void** stream) {
 // ---- the steps right behind the path, on results still on the device -----------------------------
 
 namespace {
-int check_epilogue(gatk_pairhmm* h, gatk_pairhmm_resident* r) {
+int check_epilogue(gatk_pairhmm*& h, gatk_pairhmm_resident* r) {
     if (int rc = check_handle(h)) return rc;
+    h = first_engine(h);
     if (!r) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "resident batch cannot be null");
     if (r->total_pairs > 0 && !r->computed) return fail(GATK_PAIRHMM_ILLEGAL_STATE, "likelihoods have not been computed yet");
     return GATK_PAIRHMM_OK;
@@ -1941,6 +2198,7 @@ extern "C" int gatk_pairhmm_compute_likelihoods_noalloc(gatk_pairhmm* h, void* s
                                                         int32_t read_max_length, int32_t haplotype_max_length,
                                                         double* device_likelihoods, int32_t* device_status) {
     if (int rc = check_handle(h)) return rc;
+    h = first_engine(h);
     const gatk_pairhmm_batch* b = device_batch;
     if (!b) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "batch cannot be null");
     if (b->num_reads < 0 || b->num_haps < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "negative read or haplotype count");

@@ -71,7 +71,7 @@ EXPORTS = [
     "gatk_pairhmm_set_option", "gatk_pairhmm_upload", "gatk_pairhmm_compute_resident", "gatk_pairhmm_download",
     "gatk_pairhmm_resident_free", "gatk_pairhmm_get_stream", "gatk_pairhmm_resident_device_output",
     "gatk_pairhmm_wait_resident", "gatk_pairhmm_normalize_resident", "gatk_pairhmm_poorly_modeled_resident",
-    "gatk_pairhmm_marginalize_resident", "gatk_pairhmm_compute_likelihoods_noalloc",
+    "gatk_pairhmm_marginalize_resident", "gatk_pairhmm_compute_likelihoods_noalloc", "gatk_pairhmm_create_multi",
 ]
 
 _lib = None
@@ -90,6 +90,7 @@ def load_library():
                 f.restype = C.c_int
         L.gatk_pairhmm_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
         L.gatk_pairhmm_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.gatk_pairhmm_create_multi.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
         L.gatk_pairhmm_initialize.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         L.gatk_pairhmm_compute_likelihoods.argtypes = [C.c_void_p, C.POINTER(CBatch), C.c_void_p]
         L.gatk_pairhmm_compute_regions.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CBatch), C.POINTER(C.c_void_p)]
@@ -235,9 +236,14 @@ class HipLoglessPairHMM:
     """PairHMM (PairHMM.java:46) implemented by the gfx950 engine."""
 
     def __init__(self, device=0):
+        """device: a GPU index, or a list of them (a multi-device instance, gatk_pairhmm_create_multi), or "all"."""
         self._lib = load_library()
         h = C.c_void_p()
-        _check(self._lib.gatk_pairhmm_create(device, C.byref(h)))
+        if isinstance(device, (list, tuple)) or device == "all":
+            devs = np.asarray([] if device == "all" else device, dtype=np.int32)
+            _check(self._lib.gatk_pairhmm_create_multi(devs.ctypes.data if devs.size else None, int(devs.size), C.byref(h)))
+        else:
+            _check(self._lib.gatk_pairhmm_create(device, C.byref(h)))
         self._h = h
         self.mLikelihoodArray = None
 

@@ -30,7 +30,7 @@ extern "C" {
 #define GATK_PAIRHMM_ILLEGAL_ARGUMENT 1    /* IllegalArgumentException (PairHMM.java:105-106,272-279; PairHMMModel.java:136-138) */
 #define GATK_PAIRHMM_ILLEGAL_STATE 2       /* IllegalStateException (PairHMM.java:271,292-295) */
 #define GATK_PAIRHMM_INDEX_OUT_OF_BOUNDS 3 /* ArrayIndexOutOfBoundsException: base quality 255 (QualityUtils.java:63,173) */
-#define GATK_PAIRHMM_DEVICE_ERROR 4        /* a HIP runtime call failed, or no gfx950 device */
+#define GATK_PAIRHMM_DEVICE_ERROR 4        /* a HIP runtime call failed, or the device is absent or not a gfx950 */
 #define GATK_PAIRHMM_OUT_OF_MEMORY 5
 
 typedef struct gatk_pairhmm gatk_pairhmm;                   /* one PairHMM instance bound to one GPU */
@@ -86,12 +86,29 @@ typedef struct gatk_pairhmm_stats {
 
 /* Constructor of a PairHMM instance on GPU `device` (replaces the JNI library's one-time
  * set-up, recalled upstream as jniInitializeClassFieldsAndMachineMask).  Fails with
- * GATK_PAIRHMM_DEVICE_ERROR when the device is absent: there is no CPU fallback. */
+ * GATK_PAIRHMM_DEVICE_ERROR when the device is absent or is not a gfx950: there is no CPU fallback. */
 int gatk_pairhmm_create(int device, gatk_pairhmm** out);
 
+/* One PairHMM instance over several GPUs of the node, for a host that is a single process (one JVM whose -nct map
+ * threads, nanoScheduler/NanoScheduler.java:112, share the node): the region-level hook the reference reserves
+ * for native back ends (PairHMM.java:129-139, "transfer all data once to the native code") hands over many
+ * regions, and regions are independent (traversals/TraverseActiveRegions.java:705-709).  devices[0 .. num_devices)
+ * lists the GPUs (a device may be listed more than once: an engine each); NULL or num_devices <= 0 = every
+ * visible device.  The handle owns one single-device engine and one host thread per entry.  compute_regions,
+ * compute_likelihoods and the calls built on them shard their regions over the engines, longest processing
+ * time first by cell count; a region worth more than half a device's share is cut by read ranges; each engine
+ * writes straight into the caller's likelihoods[k].  No gather copy and nothing between GPUs.  A call of fewer
+ * than "multi_min_pairs" pairs (option, default 8192) goes to one engine, the engines taking such calls in
+ * turn.  set_option and initialize apply to every engine; stats add the counts up and report the slowest
+ * device's times.  The resident interface, the allocation-free entry point and get_stream are served by the
+ * first device's engine.  The handle option "combine_calls" has no effect on such a handle.  Same threading
+ * rule: one handle, one thread at a time. */
+int gatk_pairhmm_create_multi(const int32_t* devices, int32_t num_devices, gatk_pairhmm** out);
+
 /* PairHMM.initialize(int readMaxLength, int haplotypeMaxLength), PairHMM.java:104-119.
- * ILLEGAL_ARGUMENT when either is <= 0.  Pre-sizes device buffers; optional, because
- * compute re-initialises when a batch exceeds the current maxima (PairHMM.java:200-201). */
+ * ILLEGAL_ARGUMENT when either is <= 0.  Optional, because a compute call whose longest read or longest
+ * haplotype exceeds the current maxima re-initialises the instance with that call's two maxima, as
+ * PairHMM.java:198-201 does (so the other maximum may shrink; compute_pair checks against them). */
 int gatk_pairhmm_initialize(gatk_pairhmm* h, int32_t read_max_length, int32_t haplotype_max_length);
 
 /* PairHMM.computeLikelihoods, PairHMM.java:190-236 (upstream JNI: jniComputeLikelihoods).

@@ -1,0 +1,164 @@
+"""The multi-device handle (gatk_pairhmm_create_multi) and the two region-stream workloads at their real sizes:
+a HaplotypeCaller-shaped stream of about 2000 active regions (30x, 151-base reads) through one compute_regions
+call, and the whole-genome-shaped 10 000 regions sharded over devices with the results written straight into the
+caller's arrays.  The GPU box has one GPU, so the multi-device handle is given device 0 twice: two engines, two
+host threads, the same sharding code as with eight distinct devices.
+
+Tolerance as in test_gpu_parity: 1e-3 in log10 against the fp64 oracle.  Two engine runs of the same region may
+differ by the fp32 error (about 2e-6) where one of them recomputed a read in fp64 because a wave-mate underflowed.
+"""
+import numpy as np
+import pytest
+
+from gatk_amd import pairhmm, sharding, synth
+from gatk_amd.pairhmm import HipLoglessPairHMM
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+SAME_ENGINE_TOL = 1e-5
+
+
+@pytest.fixture(scope="session")
+def hc_regions():
+    """2000 HaplotypeCaller-shaped regions (about 130 k reads, 1 M pairs, 56 G cells), generated once per session."""
+    return synth.make_regions(2000, seed=synth.DEFAULT_SEED)
+
+
+@pytest.fixture(scope="module")
+def multi():
+    h = HipLoglessPairHMM([0, 0])
+    yield h
+    h.close()
+
+
+def ref(oracle, b):
+    rc, out = oracle.compute_likelihoods(b, oracle.LOGLESS, fast_threads=8)
+    assert rc == 0
+    return out
+
+
+def check_against_oracle(oracle, regions, outs, sample):
+    for k in sample:
+        want, got = ref(oracle, regions[k]), outs[k]
+        assert got.shape == want.shape
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin)
+        assert float(np.abs(got[fin] - want[fin]).max()) <= TOL, f"region {k}"
+
+
+def check_valid(regions, outs):
+    assert len(outs) == len(regions)
+    for b, o in zip(regions, outs):
+        assert o.shape == (b.num_reads, b.num_haps)
+        assert not np.isnan(o).any() and (o <= 0).all()
+
+
+def assert_same(a, b, tol=SAME_ENGINE_TOL):
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.array_equal(np.isfinite(x), np.isfinite(y))
+        fin = np.isfinite(x)
+        if fin.any():
+            assert float(np.abs(x[fin] - y[fin]).max()) <= tol
+
+
+def test_haplotypecaller_stream_at_size(hmm, oracle, hc_regions):
+    outs = hmm.compute_regions(hc_regions)
+    st = hmm.stats()
+    assert st["pairs"] == sum(b.num_reads * b.num_haps for b in hc_regions)
+    assert st["cells"] == sum(b.cells for b in hc_regions)
+    check_valid(hc_regions, outs)
+    rng = np.random.default_rng(5)
+    check_against_oracle(oracle, hc_regions, outs, rng.choice(len(hc_regions), size=50, replace=False))
+
+
+def test_multi_device_handle_matches_single_device(hmm, multi, oracle, hc_regions):
+    # 300 regions plus one batch large enough to be cut by read ranges between the engines, and two empty regions
+    big = synth.make_batch(1536, 32, 151, 600, seed=21, hap_len_jitter=0)
+    empty = synth.make_batch(0, 3, 10, 30, seed=1)
+    regions = hc_regions[:150] + [empty, big] + hc_regions[150:300] + [empty]
+    single = hmm.compute_regions(regions)
+    got = multi.compute_regions(regions)
+    st = multi.stats()
+    assert st["pairs"] == sum(b.num_reads * b.num_haps for b in regions) and st["cells"] == sum(b.cells for b in regions)
+    check_valid(regions, got)
+    assert_same(got, single)
+    check_against_oracle(oracle, regions, got, [0, 77, 151, 152, 299])
+    # one computeLikelihoods call on the multi-device handle: the large batch is split, the small one goes to one engine
+    assert_same([multi.compute_batch(big)], [single[151]])
+    small = hc_regions[7]
+    for _ in range(3):  # the engines take small calls in turn
+        assert_same([multi.compute_batch(small)], [single[7]])
+    assert np.array_equal(multi.getLikelihoodArray(), multi.compute_batch(small).reshape(-1))
+
+
+def test_multi_device_handle_options_errors_and_single_pair(multi, oracle, hc_regions):
+    regions = hc_regions[300:420]
+    multi.set_option("force_fp64", 1)
+    try:
+        got = multi.compute_regions(regions)
+    finally:
+        multi.set_option("force_fp64", 0)
+    for k in (0, 60, 119):
+        want = ref(oracle, regions[k])
+        fin = np.isfinite(want)
+        assert float(np.abs(got[k][fin] - want[fin]).max()) <= 1e-9
+    # the reference's exception reaches the caller whichever engine met it
+    bad = synth.make_batch(40, 6, 100, 300, seed=3)
+    bad.gcp = bad.gcp.copy(); bad.gcp[11] = 200
+    with pytest.raises(pairhmm.IllegalArgumentException):
+        multi.compute_regions(regions[:60] + [bad] + regions[60:])
+    with pytest.raises(pairhmm.IllegalArgumentException, match="region 3"):  # host-side checks name the caller's region index
+        worse = synth.make_batch(4, 2, 20, 50, seed=3)
+        worse.hap_offsets = worse.hap_offsets.copy(); worse.hap_offsets[1] = worse.hap_offsets[0]
+        multi.compute_regions(regions[:3] + [worse])
+    # and the handle is usable afterwards
+    assert_same(multi.compute_regions(regions[:5]), [ref(oracle, b) for b in regions[:5]], tol=TOL)
+    # initialize and the single-pair call go to every engine
+    multi.initialize(200, 700)
+    b = regions[0]
+    lo, hi = int(b.read_offsets[0]), int(b.read_offsets[1])
+    hap = bytes(b.hap_bases[int(b.hap_offsets[0]):int(b.hap_offsets[1])])
+    lk = multi.computeReadLikelihoodGivenHaplotypeLog10(hap, bytes(b.read_bases[lo:hi]), b.read_quals[lo:hi], b.ins_gop[lo:hi],
+                                                        b.del_gop[lo:hi], b.gcp[lo:hi])
+    assert abs(lk - ref(oracle, b)[0, 0]) <= TOL
+
+
+def test_whole_genome_shaped_10k_regions_sharded(hmm, multi, oracle, hc_regions):
+    # 10 000 regions: five differently ordered passes over the 2000 generated ones
+    rng = np.random.default_rng(9)
+    index = np.concatenate([rng.permutation(len(hc_regions)) for _ in range(5)])
+    regions = [hc_regions[i] for i in index]
+    pairs = sum(b.num_reads * b.num_haps for b in regions)
+    cells = sum(b.cells for b in regions)
+    # through the process-per-GPU sharding helper (world 1: everything on this rank) ...
+    sharded = sharding.compute_sharded(regions, hmm.compute_regions, rank=0, world=1)
+    st = hmm.stats()
+    assert st["pairs"] == pairs and st["cells"] == cells
+    check_valid(regions, sharded)
+    # ... and through the multi-device handle, which shards inside the C-ABI
+    got = multi.compute_regions(regions)
+    st = multi.stats()
+    assert st["pairs"] == pairs and st["cells"] == cells
+    check_valid(regions, got)
+    assert_same(got, sharded)
+    # order independence: the five copies of a region agree wherever they landed
+    first = {}
+    for pos, i in enumerate(index):
+        if i in first:
+            assert_same([got[pos]], [got[first[i]]])
+        else:
+            first[i] = pos
+    sample = rng.choice(len(regions), size=50, replace=False)
+    check_against_oracle(oracle, regions, got, sample)
+
+
+def test_device_list_of_the_whole_node():
+    h = HipLoglessPairHMM("all")  # every visible device
+    try:
+        b = synth.config_c1()
+        assert h.compute_batch(b).shape == (128, 16)
+    finally:
+        h.close()
+    with pytest.raises(pairhmm.DeviceError):
+        HipLoglessPairHMM([0, 99])
