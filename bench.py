@@ -1,23 +1,35 @@
 #!/usr/bin/env python3
 """PairHMM GCUPS benchmark.
 
-A step is one pass of the hot path over one synthetic batch that is already resident in HBM:
-input validation, expansion of reads and haplotypes, the fp32 forward kernel, the conversion of its
-sums to log10 and the fp64 rerun of underflowing work items, all enqueued through the C-ABI
-(gatk_pairhmm_compute_resident).  The K timed steps are enqueued back to back on the engine's stream
-and waited for once; the engine brackets every pass with HIP events on that stream, so the kernel
-time in the roofline object is the average over exactly the timed passes.  The default workload is the
-large-batch configuration the GCUPS metric is quoted on: 4096 reads x 64 haplotypes, 151 bp /
-600 bp.  With N GPUs every rank scores its own batch of that shape (pairs are independent:
-no data-path collective), so scaling is weak and value = N * cells / max-over-ranks time.
+A step is one pass of the hot path over one synthetic batch: input validation, expansion of reads and
+haplotypes, the fp32 forward kernel, the conversion of its sums to log10 and the fp64 rerun of underflowing
+pairs, all through the C-ABI.  The default workload is the large-batch configuration the GCUPS metric is quoted
+on: 4096 reads x 64 haplotypes, 151 bp / 600 bp.
+
+Two timed legs of K steps each, both bracketed by barrier + device synchronisation:
+  * resident  (`value`): the batch is already in HBM when the clock starts (gatk_pairhmm_compute_resident);
+    the K passes are enqueued back to back and waited for once.  The engine brackets every pass with HIP events
+    on its own stream, so the kernel time of the roofline object is the average over exactly these passes.
+  * end to end (`end_to_end`): K calls of gatk_pairhmm_compute_likelihoods on host arrays: checks, planning, the
+    host-to-device copy, every kernel, the copy back into the caller's array.  Includes PCIe.
+
+On rank 0 of a one-GPU run the other workloads follow, each through the host-pointer entry points (`configs`):
+the 128 x 16 CPU-sized batch, the 250 / 1000 high-indel batch with its fp64 rerun rate, a HaplotypeCaller-shaped
+stream of 2000 active regions in one compute_regions call, and one region per call.  Then the CPU baseline on a
+bounded sample.  With N GPUs every rank scores its own batch of the default shape (pairs are independent: no
+data-path collective), so scaling is weak and value = N * cells / max-over-ranks time; the `c4` object adds the
+whole-genome-shaped 10 000 regions, sharded over the ranks with the host gather inside the clock (strong scaling).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
 import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -25,8 +37,10 @@ sys.path.insert(0, ROOT)
 FLOP_PER_CELL = 12          # 8 mul + 4 add of the linear-space three-state recurrence
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X: 256 CU x 4 SIMD x 32 lanes x 2 FLOP x 2.4 GHz
 # HBM bytes of one fp32 forward launch on the default workload, from PMC counters collected in a run
-# of their own (2 x FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_stream_kernel.txt); not measured live
+# of their own (2 x FETCH_SIZE + WRITE_SIZE); not measured live
 PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD = 2 * 10287.9e3 + 6858.8e3
+PMC_TRAFFIC_SOURCE = "profiles/r01_pmc_stream_kernel.txt (separate --pmc passes of this command; not measured in this run)"
+EMIT_MODES = {0: "compare", 1: "compare+N", 2: "table", 3: "table+N"}
 
 
 def cpu_model():
@@ -40,6 +54,18 @@ def cpu_model():
     return "unknown CPU"
 
 
+def host_threads():
+    """Threads the CPU legs may use: every core this process is allowed (scheduler affinity), capped by the
+    OMP_NUM_THREADS the GPU box sets for its one-GPU share of the machine."""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    omp = os.environ.get("OMP_NUM_THREADS", "")
+    limit = int(omp) if omp.isdigit() and int(omp) > 0 else allowed
+    return max(1, min(allowed, limit)), allowed, omp or None
+
+
 def timed_sample(fn, batch, threads, target_seconds):
     """Run fn on the first reads of the batch: a probe to size the sample, then about target_seconds of work."""
     probe = batch.read_slice(0, min(batch.num_reads, 4 * threads))
@@ -49,6 +75,7 @@ def timed_sample(fn, batch, threads, target_seconds):
     rate = probe.cells / dt
     n = int(min(batch.num_reads, max(probe.num_reads, target_seconds * rate / (batch.cells / batch.num_reads))))
     n = max(threads, n - n % threads)
+    n = min(n, batch.num_reads)
     sample = batch.read_slice(0, n)
     # the whole batch may take well under the target: repeat it
     reps = max(1, min(200, int(target_seconds * rate / sample.cells)))
@@ -65,7 +92,7 @@ def cpu_baseline(batch, target_seconds=8.0):
     is the reported value; the scalar fp64 restatement (the parity oracle) is timed beside it."""
     from oracle import oracle as O
 
-    threads = max(1, min(16, os.cpu_count() or 1))
+    threads, allowed, omp = host_threads()
 
     def simd(b):
         assert O.simd_compute_likelihoods(b, threads)[0] == 0
@@ -76,10 +103,96 @@ def cpu_baseline(batch, target_seconds=8.0):
     s1, n1, dt1, reps1 = timed_sample(simd, batch, threads, target_seconds)
     s2, n2, dt2, reps2 = timed_sample(scalar, batch, threads, target_seconds)
     return {"value": round(s1.cells / dt1 / 1e9, 3), "unit": "GCUPS", "cores": threads, "kind": "port",
+            "host": {"cpu": cpu_model(), "os_cpu_count": os.cpu_count(), "cpus_in_affinity_mask": allowed, "OMP_NUM_THREADS": omp,
+                     "threads_used": threads,
+                     "note": "every core this process may use; the GPU box gives a one-GPU job OMP_NUM_THREADS cores of the machine"},
             "sample": f"first {n1} of {batch.num_reads} reads x {batch.num_haps} haplotypes of the same batch ({s1.cells:.3e} cells, "
                       f"{reps1} x {dt1:.2f} s), fp32 with fp64 redo, {O.simd_isa()} vectors over haplotypes, OpenMP over reads, on {cpu_model()}",
             "scalar_fp64_oracle": {"value": round(s2.cells / dt2 / 1e9, 3), "unit": "GCUPS", "cores": threads,
                                    "sample": f"first {n2} reads ({s2.cells:.3e} cells, {reps2} x {dt2:.2f} s), OpenMP over reads"}}
+
+
+class HostCall:
+    """One prepared C-ABI call on host arrays: ctypes views and the output arrays are made once, the clock covers
+    the library call only."""
+
+    def __init__(self, hmm, regions, single):
+        from gatk_amd import pairhmm
+        self.lib, self.hmm, self.regions, self.single = pairhmm.load_library(), hmm, regions, single
+        self.keep = []
+        self.outs = [np.full((b.num_reads, b.num_haps), np.nan, dtype=np.float64) for b in regions]
+        self.cbs = (pairhmm.CBatch * len(regions))(*[pairhmm.to_cbatch(b, self.keep) for b in regions])
+        self.arr = (C.c_void_p * len(regions))(*[o.ctypes.data if o.size else None for o in self.outs])
+        self.cells = sum(b.cells for b in regions)
+        self.pairs = sum(b.num_reads * b.num_haps for b in regions)
+
+    def __call__(self):
+        if self.single:
+            rc = self.lib.gatk_pairhmm_compute_likelihoods(self.hmm._h, C.byref(self.cbs[0]), self.arr[0])
+        else:
+            rc = self.lib.gatk_pairhmm_compute_regions(self.hmm._h, len(self.regions), self.cbs, self.arr)
+        if rc != 0:
+            raise RuntimeError(self.lib.gatk_pairhmm_last_error().decode())
+
+    def check(self):
+        for o in self.outs:
+            assert not np.isnan(o).any() and bool((o <= 0).all())
+
+
+def time_calls(call, reps, warm=3):
+    for _ in range(warm):
+        call()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        call()
+        ts.append(time.perf_counter() - t0)
+    call.check()
+    return float(np.median(ts)), float(np.min(ts))
+
+
+def leg(call, reps, what):
+    med, best = time_calls(call, reps)
+    return {"workload": what, "pairs": call.pairs, "cells": call.cells, "wall_ms": round(med * 1e3, 4), "best_ms": round(best * 1e3, 4),
+            "gcups": round(call.cells / med / 1e9, 1), "calls_timed": reps, "path": "host arrays in, host arrays out (plan + H2D + kernels + D2H)"}
+
+
+def other_configs(device, hc_regions):
+    """The other named workloads on one GPU, each through the host-pointer entry points on a default handle."""
+    from gatk_amd import synth
+    from gatk_amd.pairhmm import HipLoglessPairHMM
+
+    out = {}
+    hmm = HipLoglessPairHMM(device)
+    try:
+        out["c1"] = leg(HostCall(hmm, [synth.config_c1()], True), 50, "128 reads (101 bp) x 16 haplotypes (~400 bp), one computeLikelihoods call")
+        c5 = synth.config_c5(num_reads=4096, num_haps=32)
+        call = HostCall(hmm, [c5], True)
+        out["c5"] = leg(call, 10, "long-read / indel stress: 4096 reads (250 bp, 4 % indels, mean Q20) x 32 haplotypes (1000 bp)")
+        st = hmm.stats()
+        out["c5"]["fp64_rerun"] = {"pairs": st["rerun_pairs"], "rate": round(st["rerun_pairs"] / max(call.pairs, 1), 6)}
+        call = HostCall(hmm, hc_regions, False)
+        out["hc_2000_regions"] = leg(call, 8, f"HaplotypeCaller-shaped stream, {len(hc_regions)} active regions (30x, 121-151 bp reads, 2-32 "
+                                              "haplotypes of 250-500 bp) in one compute_regions call")
+        out["hc_2000_regions"]["us_per_region"] = round(out["hc_2000_regions"]["wall_ms"] * 1e3 / len(hc_regions), 2)
+        # one region per call: how the reference's likelihood engine calls a PairHMM (PairHMM.java:190, once per region and sample)
+        calls = [HostCall(hmm, [b], True) for b in hc_regions[:300]]
+        for c in calls[:20]:
+            c()
+        lat = []
+        t_all = time.perf_counter()
+        for c in calls:
+            t0 = time.perf_counter()
+            c()
+            lat.append(time.perf_counter() - t0)
+        t_all = time.perf_counter() - t_all
+        cells = sum(c.cells for c in calls)
+        out["one_region_per_call"] = {"workload": "300 of those regions, one compute_likelihoods call each, one caller thread",
+                                      "median_us": round(float(np.median(lat)) * 1e6, 1), "p90_us": round(float(np.percentile(lat, 90)) * 1e6, 1),
+                                      "gcups": round(cells / t_all / 1e9, 1), "mean_pairs_per_call": round(sum(c.pairs for c in calls) / len(calls), 1)}
+    finally:
+        hmm.close()
+    return out
 
 
 def main():
@@ -90,7 +203,14 @@ def main():
     ap.add_argument("--reads", type=int, default=4096)
     ap.add_argument("--haps", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other workloads (profiling runs)")
     args = ap.parse_args()
+
+    # stdout carries the one JSON line and nothing else: whatever libraries print while they set up (gloo announces
+    # its connections there) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
 
@@ -109,14 +229,17 @@ def main():
     torch.cuda.set_device(local_rank)
     reduce_device = "cuda" if backend == "nccl" else "cpu"
     dist = None
+    host_group = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            host_group = dist.new_group(backend="gloo")  # the host gather of the c4 leg: CPU arrays, no device collective
         else:
             dist.init_process_group(backend)
+            host_group = dist.group.WORLD
 
-    from gatk_amd import synth
+    from gatk_amd import sharding, synth
     from gatk_amd.pairhmm import HipLoglessPairHMM
 
     # every rank scores a batch of the same shape (different seed): weak scaling
@@ -130,6 +253,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=reduce_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([float(x)], dtype=torch.float64, device=reduce_device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    # ---- resident leg: inputs in HBM when the clock starts ----------------------------------------------------
     for _ in range(args.warmup):
         res.compute(sync=True)
     barrier()
@@ -143,24 +281,82 @@ def main():
     assert st["timed_passes"] == args.steps
     fp32_ms, fp64_ms, aux_ms = st["fp32_kernel_ms"], st["fp64_kernel_ms"], st["aux_kernel_ms"]
     rerun_pairs = st["rerun_pairs"] * args.steps  # every pass scores the same batch
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([float(batch.cells)], dtype=torch.float64, device=reduce_device)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total_cells = float(c.item())
-    else:
-        total_cells = float(batch.cells)
+    elapsed = max_over_ranks(elapsed)
+    total_cells = sum_over_ranks(batch.cells)
 
     # sanity: results of the last step are finite log10 likelihoods <= 0
     out = res.download()[0]
     assert out.shape == (batch.num_reads, batch.num_haps) and bool((out <= 0).all())
+    res.free()
+    hmm.close()
+
+    # ---- end-to-end leg: host arrays in, host arrays out, on a handle with the default options ------------------
+    hmm = HipLoglessPairHMM(local_rank)
+    call = HostCall(hmm, [batch], True)
+    for _ in range(args.warmup):
+        call()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        call()
+    barrier()
+    e2e = max_over_ranks(time.perf_counter() - t0)
+    call.check()
+    assert float(np.abs(call.outs[0] - out).max()) <= 1e-5  # the two legs score the same batch
+    hmm.close()
+
+    # ---- N > 1: the whole-genome-shaped workload, sharded over the ranks, host gather inside the clock ---------
+    c4 = None
+    if world > 1:
+        base = synth.make_regions(2000, seed=synth.DEFAULT_SEED)
+        order = np.concatenate([np.random.default_rng(9).permutation(len(base)) for _ in range(5)])
+        regions = [base[i] for i in order]  # 10 000 regions; the same list on every rank
+        hmm = HipLoglessPairHMM(local_rank)
+        try:
+            # the assignment and this rank's marshalled call are made once, as a host that holds its arrays would
+            shards = sharding.shard_regions(regions, world)
+            prepared = hmm.prepare_regions([regions[i] for i in shards[rank]])
+            times = []
+            for it in range(4):
+                barrier()
+                t0 = time.perf_counter()
+                gathered = sharding.compute_sharded(regions, lambda _mine: prepared.compute(), rank=rank, world=world,
+                                                    gather_group=host_group, shards=shards)
+                barrier()
+                times.append(max_over_ranks(time.perf_counter() - t0))
+            if rank == 0:
+                assert len(gathered) == len(regions) and all(g.shape == (b.num_reads, b.num_haps) and bool((g <= 0).all()) for g, b in zip(gathered, regions))
+                cells = sum(b.cells for b in regions)
+                c4 = {"workload": "10 000 HaplotypeCaller-shaped regions (five orderings of 2000 generated ones) sharded over the ranks, "
+                                  "longest processing time first by cells; results gathered on rank 0's host (gloo)",
+                      "scaling": "strong", "cells": cells, "pairs": sum(b.num_reads * b.num_haps for b in regions),
+                      "wall_ms": round(min(times[1:]) * 1e3, 2), "first_ms": round(times[0] * 1e3, 2),
+                      "gcups": round(cells / min(times[1:]) / 1e9, 1), "includes": "planning, H2D, kernels, D2H on every rank, then the host gather of the likelihood arrays on rank 0"}
+        finally:
+            hmm.close()
+        # and the same list through ONE process driving every GPU (the multi-device handle a single JVM would hold),
+        # while the other ranks wait at a host-side barrier (a device-side one would keep their GPUs spinning)
+        if rank == 0:
+            try:
+                devices = [r % torch.cuda.device_count() for r in range(world)]
+                multi = HipLoglessPairHMM(devices)
+                mcall = HostCall(multi, regions, False)
+                med, best = time_calls(mcall, 3, warm=2)
+                multi.close()
+                c4["one_process_all_gpus"] = {"wall_ms": round(best * 1e3, 2), "gcups": round(mcall.cells / best / 1e9, 1),
+                                              "path": "gatk_pairhmm_create_multi + one compute_regions call: sharded inside the C-ABI, "
+                                                      "engines write into the caller's arrays, no gather copy"}
+            except Exception as e:  # never lose the line over the extra leg
+                c4["one_process_all_gpus"] = {"error": repr(e)}
+        dist.barrier(group=host_group)
 
     if rank == 0:
         steps = max(args.steps, 1)
         kern_s = fp32_ms / steps * 1e-3
         achieved = batch.cells * FLOP_PER_CELL / kern_s / 1e12
+        kernel = (f"{'fwd_stream' if st['main_stream_pass'] else 'fwd_direct'}<{st['main_rows_per_lane']}, "
+                  f"{EMIT_MODES.get(st['main_emit_mode'], st['main_emit_mode'])}> (fp32 forward pass)")
+        default_shape = (args.reads, args.haps) == (4096, 64)
         line = {
             "metric": "PairHMM GCUPS", "value": round(total_cells * steps / elapsed / 1e9, 2), "unit": "GCUPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,22 +364,30 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"large-batch PairHMM: {args.reads} reads x {args.haps} haplotypes, 151 bp / 600 bp, per GPU",
                        "cells_per_gpu_step": batch.cells, "pairs_per_gpu_step": batch.num_reads * batch.num_haps,
+                       "value_is": "resident pass: the batch is in HBM when the clock starts; every kernel of a pass is inside it",
                        "parallelism": f"independent batches on {world} GPU(s), host gather, no collective"},
+            "resident_gcups": round(total_cells * steps / elapsed / 1e9, 2),
+            "end_to_end": {"gcups": round(total_cells * steps / e2e / 1e9, 2), "ms_per_call": round(e2e / steps * 1e3, 4), "calls_timed": args.steps,
+                           "path": "gatk_pairhmm_compute_likelihoods on host arrays: checks + planning + H2D + kernels + fp64 reruns + D2H"},
             "roofline": {"bound": "valu", "bound_detail": "fp32 vector ALU (a recurrence: neither HBM- nor MFMA-bound)",
-                         "kernel": "fwd_stream<10, 2> (fp32 forward pass)", "achieved": round(achieved, 2), "peak": PEAK_FP32_VALU_TFLOPS,
+                         "kernel": kernel, "achieved": round(achieved, 2), "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
-                         "traffic": PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD if (args.reads, args.haps) == (4096, 64) else None,
+                         "traffic": PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD if default_shape else None,
+                         "traffic_source": PMC_TRAFFIC_SOURCE if default_shape else None,
                          "flop_per_cell": FLOP_PER_CELL, "kernel_ms": round(fp32_ms / steps, 4),
                          "kernel_gcups": round(batch.cells / kern_s / 1e9, 1)},
             "other_kernels_ms": round(aux_ms / steps, 4),
             "fp64_rerun": {"pairs_per_step": rerun_pairs // steps, "rate": round(rerun_pairs / steps / (batch.num_reads * batch.num_haps), 6),
                            "kernel_ms": round(fp64_ms / steps, 4)},
         }
+        if c4 is not None:
+            line["c4"] = c4
+        if world == 1 and not args.no_configs:
+            line["configs"] = other_configs(local_rank, synth.make_regions(2000, seed=synth.DEFAULT_SEED))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(batch)
-        print(json.dumps(line), flush=True)
-    res.free()
-    hmm.close()
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

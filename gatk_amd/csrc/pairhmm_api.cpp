@@ -165,7 +165,9 @@ struct PinnedBuf {
     }
 };
 
-constexpr size_t kCounterBytes = 256;  // device counters of a pass: error word, rerun-list lengths, pair-list lengths
+constexpr size_t kCounterBytes = 256;  // device counters of a pass: error word, rerun-list lengths, pair-list lengths, first bad read
+constexpr int kErrorReadSlot = 1 + 2 * kMaxBuckets;  // counters[kErrorReadSlot]: INT32_MAX - index of the first read with an input error, 0 = none
+static_assert((kErrorReadSlot + 1) * sizeof(int32_t) <= kCounterBytes, "counter block");
 
 struct Bucket {
     int rows_per_lane = 0;
@@ -190,6 +192,8 @@ struct gatk_pairhmm_resident {
     // ---- host-side plan ----
     hipStream_t stream = nullptr;  // every copy and kernel of this batch is ordered on it
     int num_regions = 0;
+    int region_label_base = 0;       // index, in the caller's region list, of this batch's first region (error messages)
+    bool regions_are_pieces = false; // the call cut large regions by read ranges: indices count the pieces
     std::vector<int64_t> region_out_off;  // [num_regions + 1] offsets into the concatenated output
     int64_t total_pairs = 0, cells = 0, total_tasks = 0;
     int64_t total_read_bytes = 0;
@@ -300,6 +304,7 @@ struct gatk_pairhmm {
     int force_rows_per_lane = 0;
     int emit_mode = -1;  // -1: table when the haplotype alphabet allows it; 0: always compare bytes
     bool squash_base_quals = false;  // base qualities under 18 count as 6 (PairHMM.java:54, QualityUtils.java:57)
+    bool no_tristate_correction = false;  // PairHMM.doNotUseTristateCorrection (PairHMM.java:83-84): mismatch prior = error probability, not a third of it
     int stream_mode = -1;  // -1: haplotype runs in table modes; 0: one haplotype per work item
     int max_stream_haps = kMaxStreamHaps;
     bool force_fp64 = false;
@@ -1039,6 +1044,8 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     B.error_word = R->counters();
     B.fp32_threshold = h->fp32_threshold;
     B.squash_base_quals = h->squash_base_quals ? 1 : 0;
+    B.mismatch_divisor = h->no_tristate_correction ? 1.0 : 3.0;
+    B.error_read = R->counters() + kErrorReadSlot;
     B.pair_counts = R->counters() + 1 + kMaxBuckets;
     const bool streaming = R->any_stream && !h->force_fp64;
     // A region-sized call on the one-haplotype pass skips the expansion launch: the forward kernel works the
@@ -1130,7 +1137,7 @@ int digest_counters(gatk_pairhmm* h, gatk_pairhmm_resident* R, const int32_t* co
 int finish_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(R->stream));
-    int32_t counters[1 + 2 * kMaxBuckets] = {0};
+    int32_t counters[kErrorReadSlot + 1] = {0};
     HIP_TRY(hipMemcpy(counters, R->counters(), sizeof counters, hipMemcpyDeviceToHost));
     return digest_counters(h, R, counters);
 }
@@ -1143,6 +1150,19 @@ int digest_counters(gatk_pairhmm* h, gatk_pairhmm_resident* R, const int32_t* co
     st.wave_tasks = R->total_tasks;
     st.host_plan_ms = R->plan_ms;
     st.host_upload_ms = R->upload_ms;
+    {
+        int64_t most = -1;
+        for (const Bucket& bk : R->buckets) {
+            const bool stream = R->streamed && bk.stream;
+            const int64_t items = stream ? bk.num_stream_tasks : bk.num_tasks;
+            if (items <= most) continue;
+            most = items;
+            st.main_rows_per_lane = bk.rows_per_lane;
+            st.main_emit_mode = h->force_fp64 ? bk.emit_mode_fp64 : bk.emit_mode;
+            st.main_stream_pass = stream ? 1 : 0;
+            st.main_fp64 = h->force_fp64 ? 1 : 0;
+        }
+    }
     for (size_t bi = 0; bi < R->buckets.size(); ++bi) {
         const Bucket& bk = R->buckets[bi];
         if (R->streamed && bk.stream) {
@@ -1181,8 +1201,20 @@ int digest_counters(gatk_pairhmm* h, gatk_pairhmm_resident* R, const int32_t* co
     R->ev_pending.clear();
     R->last_timing = st;
     h->stats = st;
-    if (counters[0] & 1) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "insert quality, deletion quality or gcp cannot be less than 0 (byte >= 128)");
-    if (counters[0] & 2) return fail(GATK_PAIRHMM_INDEX_OUT_OF_BOUNDS, "base quality 255 is outside the 255-entry error-probability cache");
+    if (counters[0] & 3) {
+        // which read: the first one (in the call's read order) that had an input error of either kind
+        std::string where;
+        if (counters[kErrorReadSlot] > 0) {
+            const int read = 0x7fffffff - counters[kErrorReadSlot];
+            int k = static_cast<int>(std::upper_bound(R->region_read_begin.begin(), R->region_read_begin.end(), read) - R->region_read_begin.begin()) - 1;
+            while (k > 0 && R->region_reads[k] == 0) --k;  // regions without reads share their successor's first index
+            if (k >= 0 && k < R->num_regions)
+                where = " (region " + std::to_string(R->region_label_base + k) + (R->regions_are_pieces ? " of the call's read-range pieces" : "") +
+                        ", read " + std::to_string(read - R->region_read_begin[k]) + ")";
+        }
+        if (counters[0] & 1) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "insert quality, deletion quality or gcp cannot be less than 0 (byte >= 128)" + where);
+        return fail(GATK_PAIRHMM_INDEX_OUT_OF_BOUNDS, "base quality 255 is outside the 255-entry error-probability cache" + where);
+    }
     return GATK_PAIRHMM_OK;
 }
 
@@ -1381,6 +1413,8 @@ static int compute_regions_single(gatk_pairhmm* h, int32_t num_regions, const ga
         }
     }
     cuts.push_back(num_regions);
+    const bool are_pieces = !pieces.empty();
+    for (gatk_pairhmm_resident* R : {&h->scratch, &h->scratch2, &h->scratch3}) { R->region_label_base = 0; R->regions_are_pieces = are_pieces; }
     if (cuts.size() <= 2) {
         if (int rc = plan_and_upload(h, &h->scratch, num_regions, regions, true)) return rc;
         if (h->scratch.total_pairs == 0) { h->stats = gatk_pairhmm_stats{}; return GATK_PAIRHMM_OK; }
@@ -1408,6 +1442,8 @@ static int compute_regions_single(gatk_pairhmm* h, int32_t num_regions, const ga
             total.rerun_tasks += st.rerun_tasks; total.rerun_pairs += st.rerun_pairs;
             total.fp32_kernel_ms += st.fp32_kernel_ms; total.fp64_kernel_ms += st.fp64_kernel_ms; total.aux_kernel_ms += st.aux_kernel_ms;
             total.timed_passes += st.timed_passes;
+            total.main_rows_per_lane = st.main_rows_per_lane; total.main_emit_mode = st.main_emit_mode;
+            total.main_stream_pass = st.main_stream_pass; total.main_fp64 = st.main_fp64;
         }
         total.host_plan_ms += R->plan_ms; total.host_upload_ms += R->upload_ms;
         return r;
@@ -1416,6 +1452,7 @@ static int compute_regions_single(gatk_pairhmm* h, int32_t num_regions, const ga
     int enqueued = 0;
     for (int p = 0; p < parts && rc == GATK_PAIRHMM_OK; ++p) {
         gatk_pairhmm_resident* R = slot[p % depth];
+        R->region_label_base = cuts[p];
         rc = plan_and_upload(h, R, cuts[p + 1] - cuts[p], regions + cuts[p], true);
         if (rc == GATK_PAIRHMM_OK && R->total_pairs > 0) rc = enqueue_compute(h, R);
         if (rc == GATK_PAIRHMM_OK) enqueued = p + 1;
@@ -1572,6 +1609,8 @@ static int compute_regions_multi(gatk_pairhmm* h, int32_t num_regions, const gat
         total.host_plan_ms = std::max(total.host_plan_ms, st.host_plan_ms);
         total.host_upload_ms = std::max(total.host_upload_ms, st.host_upload_ms);
         total.timed_passes = std::max(total.timed_passes, st.timed_passes);
+        if (d == 0) { total.main_rows_per_lane = st.main_rows_per_lane; total.main_emit_mode = st.main_emit_mode;
+                      total.main_stream_pass = st.main_stream_pass; total.main_fp64 = st.main_fp64; }
     }
     h->stats = total;
     for (int d = 0; d < n_dev; ++d)
@@ -1701,7 +1740,7 @@ int gatk_pairhmm_compute_likelihoods(gatk_pairhmm* h, const gatk_pairhmm_batch* 
     double* outs[1] = {likelihoods};
     // combined: a call that cannot fill the device by itself, on a handle whose other options are the defaults
     const bool plain = h->fp32_threshold == 1e-28f && h->force_rows_per_lane == 0 && !h->force_fp64 && h->emit_mode == -1 &&
-                       h->stream_mode == -1 && !h->timing;
+                       h->stream_mode == -1 && !h->timing && !h->no_tristate_correction;
     if (h->combine_calls && h->children.empty() && plain && n < 4 * static_cast<int64_t>(h->wave_slots)) {
         int read_max = 0, hap_max = 0;
         if (int rc = check_region(*batch, 0, &read_max, &hap_max)) return rc;
@@ -1886,6 +1925,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
     else if (n == "timing") h->timing = value != 0;
     else if (n == "stream_mode") h->stream_mode = static_cast<int>(value);
     else if (n == "squash_base_quals") h->squash_base_quals = value != 0;
+    else if (n == "do_not_use_tristate_correction") h->no_tristate_correction = value != 0;
     else if (n == "pipeline_pairs") h->pipeline_pairs = std::max<int64_t>(0, static_cast<int64_t>(value));
     else if (n == "pipeline_ramp") h->pipeline_ramp = value != 0;
     else if (n == "pipeline_depth") h->pipeline_depth = value >= 3 ? 3 : 2;
@@ -2251,6 +2291,7 @@ extern "C" int gatk_pairhmm_compute_likelihoods_noalloc(gatk_pairhmm* h, void* s
     B.read_bases = b->read_bases; B.read_quals = b->read_quals; B.ins_gop = b->ins_gop; B.del_gop = b->del_gop; B.gcp = b->gcp;
     B.read_mapq = b->read_mapq;
     B.squash_base_quals = h->squash_base_quals ? 1 : 0;
+    B.mismatch_divisor = h->no_tristate_correction ? 1.0 : 3.0;
     B.read_off = b->read_offsets;
     B.read_out_base = reinterpret_cast<const int32_t*>(S + noalloc::at_read_out_base);
     B.hap_pool = S + noalloc::at_hap_pool;

@@ -121,6 +121,7 @@ struct DeviceBatch {
     const uint8_t* gcp;
     const uint8_t* read_mapq;      // [num_reads] cap on the read's base qualities, or null
     int32_t squash_base_quals;     // 1: base qualities under 18 count as 6
+    double mismatch_divisor;       // 3: the tristate correction of Log10PairHMM.java:157; 1 with doNotUseTristateCorrection
     const int32_t* read_off;       // [num_reads + 1]
     const int32_t* read_out_base;  // [num_reads] index in out[] of (read, haplotype 0 of its region)
     const uint8_t* hap_pool;       // haplotype bytes, each haplotype starting on a 16-byte boundary
@@ -161,6 +162,7 @@ struct DeviceBatch {
     int64_t total_read_bytes;
     const int32_t* neg_inf_idx;    // [num_neg_inf] indices in out[] of the pairs of zero-length reads
     int32_t num_neg_inf;
+    int32_t* error_read;           // slot for the first read with an input error, kept as INT32_MAX - read index (atomicMax); may be null
     // Set only by passes whose descriptors are written on the device: the one-haplotype kernels leave at once
     // when bit kAbortBit of this word is set (the descriptors are then not to be trusted).  Null otherwise.
     const int32_t* abort_word;

@@ -89,6 +89,13 @@ __device__ __forceinline__ unsigned effective_qual(const DeviceBatch& B, const i
     return q;
 }
 
+// An input error found on the device: the kind goes into the error word, the smallest read index that had one
+// into error_read (kept as INT32_MAX - index, so that zero means none and atomicMax keeps the first read).
+__device__ __forceinline__ void report_input_error(const DeviceBatch& B, const int bad, const int read) {
+    atomicOr(B.error_word, bad);
+    if (B.error_read != nullptr && read >= 0) atomicMax(B.error_read, 0x7fffffff - read);
+}
+
 // Keeps a per-row constant in a register of its own type: without it the compiler carries the
 // double it was converted from through the loop and converts after every select.
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
@@ -187,12 +194,13 @@ __device__ __forceinline__ RowConst make_row_const(const DeviceBatch& B, const i
         const unsigned x = B.read_bases[ro + i - 1];
         const unsigned ins_byte = B.ins_gop[ro + i - 1], del_byte = B.del_gop[ro + i - 1], gcp_byte = B.gcp[ro + i - 1];
         if ((ins_byte | del_byte | gcp_byte) & 0x80u) bad |= 1;
-        if (B.read_quals[ro + i - 1] == 255) bad |= 2;
-        const double e = B.err_prob[effective_qual(B, ro + i - 1, read)];
+        const unsigned qual = effective_qual(B, ro + i - 1, read);  // what the PairHMM is handed: after the mapping-quality cap
+        if (qual == 255) bad |= 2;
+        const double e = B.err_prob[qual];
         const unsigned ins = ins_byte & 127u, del = del_byte & 127u;
         const double t0 = B.match_to_match[ins * 128u + del];
         const double p = 1.0 - e;
-        const double q = (x == 'N') ? p : e / 3.0;  // a read 'N' matches every base
+        const double q = (x == 'N') ? p : e / B.mismatch_divisor;  // a read 'N' matches every base
         t2 = B.err_prob[ins];
         t4 = B.err_prob[del];
         c.p_match = static_cast<float>(p * t0);
@@ -327,7 +335,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
                 c0[r] = make_float4(c.p_match, c.p_mismatch, c.t5, c.c_f);
                 c1[r] = make_float4(c.c_i, c.c_e, __uint_as_float(c.base), 0.0f);
             }
-            if (bad) atomicOr(B.error_word, bad);
+            if (bad) report_input_error(B, bad, ld.read_idx);
         }
 #pragma unroll
         for (int r = 0; r < K; ++r) {
@@ -374,7 +382,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
                     const double e = B.err_prob[effective_qual(B, ro + i - 1, ld.read_idx)];
                     xb = x;
                     p = 1.0 - e;                         // QualityUtils.qualToProb
-                    q = (x == 'N') ? p : e / 3.0;        // a read 'N' matches every base
+                    q = (x == 'N') ? p : e / B.mismatch_divisor;        // a read 'N' matches every base
                     t4 = B.err_prob[B.del_gop[ro + i - 1] & 127u];  // matchToDeletion
                     t5 = B.err_prob[B.gcp[ro + i - 1]];             // deletionToDeletion
                 } else {
@@ -877,7 +885,7 @@ __device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_
                 const double e = B.err_prob[effective_qual(B, ro + i - 1, pr.read_idx)];
                 xc = (x == 'A' ? 0u : x == 'C' ? 1u : x == 'T' ? 2u : x == 'G' ? 3u : 0x7fu) * kLutCodeStride;
                 p = 1.0 - e;
-                q = (x == 'N') ? p : e / 3.0;
+                q = (x == 'N') ? p : e / B.mismatch_divisor;
                 t4 = B.err_prob[B.del_gop[ro + i - 1] & 127u];
                 t5 = B.err_prob[B.gcp[ro + i - 1]];
             } else {
@@ -1081,7 +1089,7 @@ __device__ __forceinline__ void prepare_read(const DeviceBatch& B, const int rea
         const RowConst c = make_row_const(B, read, ro, R, i, bad);
         if (expand) dst[i] = c;
     }
-    if (bad) atomicOr(B.error_word, bad);
+    if (bad) report_input_error(B, bad, read);
 }
 
 // Everything a pass needs before its forward kernels, in one launch.  Blocks [0, read_blocks) take

@@ -58,7 +58,8 @@ class CStats(C.Structure):
     _fields_ = [("pairs", C.c_int64), ("cells", C.c_int64), ("wave_tasks", C.c_int64), ("rerun_tasks", C.c_int64),
                 ("rerun_pairs", C.c_int64), ("fp32_kernel_ms", C.c_double), ("fp64_kernel_ms", C.c_double),
                 ("host_plan_ms", C.c_double), ("host_upload_ms", C.c_double), ("aux_kernel_ms", C.c_double),
-                ("timed_passes", C.c_int64)]
+                ("timed_passes", C.c_int64), ("main_rows_per_lane", C.c_int32), ("main_emit_mode", C.c_int32),
+                ("main_stream_pass", C.c_int32), ("main_fp64", C.c_int32)]
 
 
 # every symbol include/gatk_pairhmm.h declares
@@ -232,6 +233,35 @@ class Resident:
             self.handle = None
 
 
+class RegionResults(list):
+    """Per-region [reads, haplotypes] arrays that are consecutive views of one buffer (`flat_buffer`)."""
+    flat_buffer = None
+
+
+class PreparedRegions:
+    """A compute_regions call whose argument marshalling is done once: the ctypes views of the caller's arrays and
+    one flat output buffer.  compute() is then the C-ABI call alone, as a host that already holds its arrays (the
+    Java side) would make it."""
+
+    def __init__(self, hmm, regions):
+        self.hmm, self.regions, self._keep = hmm, list(regions), []
+        n = len(self.regions)
+        self._cbs = (CBatch * max(1, n))(*[to_cbatch(b, self._keep) for b in self.regions])
+        sizes = [b.num_reads * b.num_haps for b in self.regions]
+        self.flat = np.full(int(sum(sizes)), np.nan, dtype=np.float64)
+        self.outs = RegionResults()
+        off = 0
+        for b, size in zip(self.regions, sizes):
+            self.outs.append(self.flat[off:off + size].reshape(b.num_reads, b.num_haps))
+            off += size
+        self.outs.flat_buffer = self.flat
+        self._arr = (C.c_void_p * max(1, n))(*[o.ctypes.data if o.size else None for o in self.outs])
+
+    def compute(self):
+        _check(self.hmm._lib.gatk_pairhmm_compute_regions(self.hmm._h, len(self.regions), self._cbs, self._arr))
+        return self.outs
+
+
 class HipLoglessPairHMM:
     """PairHMM (PairHMM.java:46) implemented by the gfx950 engine."""
 
@@ -283,6 +313,9 @@ class HipLoglessPairHMM:
         addresses, stream a hipStream_t address (None: the default stream).  Enqueues and returns; allocates nothing."""
         _check(self._lib.gatk_pairhmm_compute_likelihoods_noalloc(self._h, stream, C.byref(cbatch), read_max_length,
                                                                   haplotype_max_length, out_ptr, status_ptr))
+
+    def prepare_regions(self, regions) -> PreparedRegions:
+        return PreparedRegions(self, regions)
 
     def upload(self, regions) -> Resident:
         keep = []

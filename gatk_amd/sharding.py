@@ -4,7 +4,9 @@ Every (read, haplotype) pair is independent (PairHMM.java:217,284 force a full r
 pair) and so is every active region (TraverseActiveRegions.java:705-709 maps them one by one),
 so the unit of distribution is the region batch, or a read range of one very large batch.  Each
 rank scores its share on its own GPU; the likelihood arrays are then gathered on the host of
-rank 0 (a gloo gather of CPU arrays).  Nothing is exchanged between GPUs.
+rank 0 (a gloo gather of CPU arrays).  Nothing is exchanged between GPUs.  A host that is one process
+uses the multi-device handle of the C-ABI instead (gatk_pairhmm_create_multi), which shards the same way
+inside the library and needs no gather.
 """
 import numpy as np
 
@@ -46,29 +48,55 @@ def split_reads(batch, num_shards):
     return [(cuts[k], cuts[k + 1]) for k in range(num_shards)]
 
 
-def compute_sharded(regions, compute_fn, rank=0, world=1, gather_group=None):
+def _gather_flat(flat, sizes, rank, world, group):
+    """Host-side gather of one float64 array per rank on rank 0: every rank knows every size (the region list and the
+    assignment are the same everywhere), so the arrays travel as plain buffers padded to the largest, without
+    pickling.  Returns the list of per-rank arrays on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    width = max(max(sizes), 1)
+    send = torch.zeros(width, dtype=torch.float64)
+    if flat.size:
+        send[:flat.size] = torch.from_numpy(np.ascontiguousarray(flat))
+    recv = [torch.empty(width, dtype=torch.float64) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, recv, dst=0, group=group)
+    if rank != 0:
+        return None
+    return [recv[r].numpy()[:sizes[r]] for r in range(world)]
+
+
+def compute_sharded(regions, compute_fn, rank=0, world=1, gather_group=None, shards=None):
     """Score `regions` (list of Batch) with `compute_fn(list_of_batches) -> list of [reads, haps]
     arrays` on this rank's share and gather on rank 0.
 
     Returns the per-region arrays in input order on rank 0 and None on the other ranks.  With
     world == 1 no process group is touched.  gather_group must be a CPU (gloo) group: the gather
-    is a host-side copy, not a GPU collective."""
-    shards = shard_regions(regions, world)
+    is a host-side copy, not a GPU collective.  `shards` (the result of shard_regions for this list and
+    world) may be passed by a caller that scores the same list more than once.  A compute_fn whose result
+    carries the arrays as consecutive views of one buffer (attribute `flat_buffer`) is gathered without a copy."""
+    if shards is None:
+        shards = shard_regions(regions, world)
     mine = shards[rank]
     outs = compute_fn([regions[i] for i in mine]) if mine else []
     if world == 1:
         return list(outs)
-    import torch.distributed as dist
-
-    payload = [(i, np.ascontiguousarray(o)) for i, o in zip(mine, outs)]
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(payload, gathered, dst=0, group=gather_group)
+    flat = getattr(outs, "flat_buffer", None)
+    if flat is None:
+        flat = np.concatenate([np.asarray(o, dtype=np.float64).reshape(-1) for o in outs]) if outs else np.zeros(0)
+    sizes = [sum(regions[i].num_reads * regions[i].num_haps for i in s) for s in shards]
+    assert flat.size == sizes[rank]
+    parts = _gather_flat(flat, sizes, rank, world, gather_group)
     if rank != 0:
         return None
     result = [None] * len(regions)
-    for part in gathered:
-        for i, o in part:
-            result[i] = o
+    for r in range(world):
+        off = 0
+        for i in shards[r]:
+            b = regions[i]
+            n = b.num_reads * b.num_haps
+            result[i] = parts[r][off:off + n].reshape(b.num_reads, b.num_haps)  # a view of the gathered buffer
+            off += n
     return result
 
 
@@ -79,10 +107,8 @@ def compute_split_batch(batch, compute_fn, rank=0, world=1, gather_group=None):
     part = compute_fn([batch.read_slice(lo, hi)])[0] if hi > lo else np.zeros((0, batch.num_haps))
     if world == 1:
         return part
-    import torch.distributed as dist
-
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(np.ascontiguousarray(part), gathered, dst=0, group=gather_group)
+    sizes = [(hi_ - lo_) * batch.num_haps for lo_, hi_ in ranges]
+    parts = _gather_flat(np.ascontiguousarray(part, dtype=np.float64).reshape(-1), sizes, rank, world, gather_group)
     if rank != 0:
         return None
-    return np.concatenate([g for g in gathered if g.shape[0] > 0], axis=0) if batch.num_reads else part
+    return np.concatenate(parts).reshape(batch.num_reads, batch.num_haps)

@@ -82,6 +82,11 @@ typedef struct gatk_pairhmm_stats {
     double aux_kernel_ms;   /* device time of the small kernels around them: validation, expansion of reads and
                                haplotypes, conversion of the fp32 sums to log10 */
     int64_t timed_passes;   /* passes the three *_kernel_ms sums cover: every compute_resident since the last wait */
+    /* the forward launch that held most of the call's work items (of the last part, for a call cut into parts) */
+    int32_t main_rows_per_lane;  /* read rows per lane of that launch (the K of the kernel instantiation) */
+    int32_t main_emit_mode;      /* 0 compares bytes, 1 same with haplotype N, 2 emission table A/C/G/T, 3 table with N */
+    int32_t main_stream_pass;    /* 1: the fp32 stream pass (haplotype runs), 0: the one-haplotype pass */
+    int32_t main_fp64;           /* 1: everything was scored in fp64 (force_fp64) */
 } gatk_pairhmm_stats;
 
 /* Constructor of a PairHMM instance on GPU `device` (replaces the JNI library's one-time
@@ -177,6 +182,9 @@ int gatk_pairhmm_device_count(int32_t* count);
  *                         device, where no wave would get a run and the one-haplotype pass saves a kernel launch.
  *   "max_stream_haps"     longest run, 1..16.
  *   "squash_base_quals"   1 = base qualities under 18 count as 6, see gatk_pairhmm_batch.
+ *   "do_not_use_tristate_correction"  1 = PairHMM.doNotUseTristateCorrection() (PairHMM.java:83-84, "only used for
+ *                         debugging purposes"): the prior of a mismatching base is the error probability itself, not
+ *                         a third of it (Log10PairHMM.java:157).
  *   "pipeline_pairs"      default 98304: a compute call with more pairs is cut, between regions and inside a
  *                         large region between reads, into parts of about that many pairs, and one part is
  *                         planned and copied while the kernels of the parts before it run; 0 = never cut.
@@ -202,7 +210,9 @@ int gatk_pairhmm_device_count(int32_t* count);
  *   "wave_slots"          waves the planner assumes the device holds at once, default 12 per CU (occupancy
  *                         experiments).
  *   "stream_lds_floor"    least bytes of LDS a wave of the fp32 stream pass asks for; a larger value lowers the
- *                         number of waves a CU holds (occupancy experiments). */
+ *                         number of waves a CU holds (occupancy experiments).
+ *   "multi_min_pairs"     multi-device handles only, default 8192: a call with fewer pairs goes to one engine on the
+ *                         calling thread. */
 int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value);
 
 /*

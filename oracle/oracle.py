@@ -48,6 +48,8 @@ def lib():
             f = getattr(L, name)
             f.argtypes = at
             f.restype = C.c_double
+        L.oracle_doNotUseTristateCorrection.argtypes = [C.c_int]
+        L.oracle_doNotUseTristateCorrection.restype = None
         L.oracle_goodLog10Probability.argtypes = [C.c_double]
         L.oracle_goodLog10Probability.restype = C.c_int
         L.oracle_jacobian_table_size.restype = C.c_int
@@ -96,6 +98,11 @@ def trans_probs(ins, dele, gcp, log10=False):
     f = lib().oracle_qualToTransProbsLog10 if log10 else lib().oracle_qualToTransProbs
     rc = f(out.ctypes.data_as(C.POINTER(C.c_double)), ins, dele, gcp)
     return rc, out
+
+
+def do_not_use_tristate_correction(on=True):
+    """PairHMM.doNotUseTristateCorrection (PairHMM.java:83-84): a switch of the whole oracle; clear it after use."""
+    lib().oracle_doNotUseTristateCorrection(1 if on else 0)
 
 
 def compute_likelihoods(batch, mode=LOGLESS, fast_threads=0):

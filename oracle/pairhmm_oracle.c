@@ -132,6 +132,12 @@ static double LN10, INV_LN10;                      /* pairhmm/PairHMMModel.java:
 
 static int oracle_ready = 0;
 
+/* PairHMM.doNotUseTristateCorrection, pairhmm/PairHMM.java:83-84 ("only used for debugging purposes"): when set,
+ * the mismatch prior is the error probability itself, not a third of it (pairhmm/Log10PairHMM.java:157).  A switch
+ * of the whole oracle, as the Java field is a switch of a PairHMM instance; tests set it and clear it again. */
+static int doNotUseTristateCorrection = 0;
+void oracle_doNotUseTristateCorrection(int on) { doNotUseTristateCorrection = on != 0; }
+
 /* Static initialisers of QualityUtils (:72-77), MathUtils.JacobianLogTable (:135-142)
  * and PairHMMModel (:114-122), in dependency order. */
 void oracle_init(void) {
@@ -273,7 +279,7 @@ static double log10_pair(int mode, n2mem *m, const uint8_t *hap, int H, const ui
         for (int j = 0; j < H; j++) {
             const uint8_t y = hap[j];
             m->prior[(i + 1) * W + (j + 1)] = (x == y || x == (uint8_t)'N' || y == (uint8_t)'N')
-                ? oracle_qualToProbLog10(qual) : (oracle_qualToErrorProbLog10(qual) - log10_3);
+                ? oracle_qualToProbLog10(qual) : (oracle_qualToErrorProbLog10(qual) - (doNotUseTristateCorrection ? 0.0 : log10_3));
         }
     }
     /* initializeMatrixValues :121-126 */
@@ -330,7 +336,7 @@ static double logless_pair(n2mem *m, const uint8_t *hap, int H, const uint8_t *r
         for (int j = 0; j < H; j++) {
             const uint8_t y = hap[j];
             m->prior[(i + 1) * W + (j + 1)] = (x == y || x == (uint8_t)'N' || y == (uint8_t)'N')
-                ? oracle_qualToProb(qual) : (oracle_qualToErrorProb(qual) / 3.0);
+                ? oracle_qualToProb(qual) : (oracle_qualToErrorProb(qual) / (doNotUseTristateCorrection ? 1.0 : 3.0));
         }
     }
     /* boundaries: linear form of pairhmm/Log10PairHMM.java:75-83,121-126 */
@@ -452,7 +458,7 @@ int oracle_logless_batch_fast(int numReads, int numHaps,
                 if (oracle_qualToTransProbs(tr + (size_t)(i + 1) * 6, insGOP[ro + i], delGOP[ro + i], gcp[ro + i])) { bad = ORACLE_ILLEGAL_ARGUMENT; break; }
                 if (readQuals[ro + i] > MAX_QUAL) { bad = ORACLE_INDEX_OUT_OF_BOUNDS; break; }
                 pm[i + 1] = oracle_qualToProb(readQuals[ro + i]);
-                pmm[i + 1] = oracle_qualToErrorProb(readQuals[ro + i]) / 3.0;
+                pmm[i + 1] = oracle_qualToErrorProb(readQuals[ro + i]) / (doNotUseTristateCorrection ? 1.0 : 3.0);
             }
             if (bad) {
 #pragma omp critical

@@ -63,3 +63,51 @@ def test_mapq_cap_and_squashing(hmm, oracle, squash):
     np.testing.assert_array_equal(got, hmm.compute_batch(pre))  # same arithmetic on the same effective qualities
     assert np.abs(got - want).max() <= 1e-3
     assert np.abs(got64 - want).max() <= 1e-9
+
+
+def test_do_not_use_tristate_correction(hmm, oracle):
+    """PairHMM.doNotUseTristateCorrection (PairHMM.java:83-84, Log10PairHMM.java:157): the mismatch prior is the
+    error probability, not a third of it.  fp32 pass, fp64 pass and the region-sized one-haplotype pass."""
+    b = synth.make_batch(40, 6, 120, 300, seed=31, qual_model="uniform")
+    rc, with_correction = oracle.compute_likelihoods(b, oracle.LOGLESS)
+    assert rc == 0
+    oracle.do_not_use_tristate_correction(True)
+    try:
+        rc, want = oracle.compute_likelihoods(b, oracle.LOGLESS)
+        assert rc == 0
+        rc, want_log10 = oracle.compute_likelihoods(b, oracle.EXACT)  # the in-tree implementation with the same switch
+        assert rc == 0
+    finally:
+        oracle.do_not_use_tristate_correction(False)
+    assert np.abs(want - want_log10).max() <= 1e-9
+    assert np.abs(want - with_correction).max() > 0.1  # the switch matters on reads with mismatches
+    hmm.set_option("do_not_use_tristate_correction", 1)
+    try:
+        for opts in ({"stream_mode": 1}, {"stream_mode": -1}, {"force_fp64": 1}):
+            for k, v in opts.items():
+                hmm.set_option(k, v)
+            got = hmm.compute_batch(b)
+            for k in opts:
+                hmm.set_option(k, {"stream_mode": 1, "force_fp64": 0}[k])
+            assert np.abs(got - want).max() <= (1e-9 if "force_fp64" in opts else 1e-3)
+    finally:
+        hmm.set_option("do_not_use_tristate_correction", 0)
+    assert np.abs(hmm.compute_batch(b) - with_correction).max() <= 1e-3
+
+
+def test_quality_255_under_a_mapping_quality_cap_is_not_an_error(hmm, oracle):
+    """The 255-entry cache is indexed with the quality the PairHMM is handed: a raw 255 that the read's mapping
+    quality caps to a usable value raises nothing; uncapped it is the reference's ArrayIndexOutOfBoundsException,
+    and the message names the region and the read."""
+    from gatk_amd import pairhmm
+    b = synth.make_batch(12, 3, 60, 150, seed=32)
+    lo = int(b.read_offsets[5])
+    b.read_quals = b.read_quals.copy(); b.read_quals[lo + 7] = 255
+    with pytest.raises(pairhmm.ArrayIndexOutOfBoundsException, match=r"region 1, read 5"):
+        hmm.compute_regions([synth.make_batch(3, 2, 30, 60, seed=1), b])
+    b.read_mapq = np.full(12, 40, dtype=np.uint8)
+    capped = synth.make_batch(12, 3, 60, 150, seed=32)
+    capped.read_quals = np.minimum(b.read_quals, 40).astype(np.uint8)
+    rc, want = oracle.compute_likelihoods(capped, oracle.LOGLESS)
+    assert rc == 0
+    assert np.abs(hmm.compute_batch(b) - want).max() <= 1e-3

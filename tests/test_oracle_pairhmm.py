@@ -180,3 +180,20 @@ def test_simd_baseline_reports_the_reference_input_errors(oracle):
     assert oracle.simd_compute_likelihoods(bad_gop)[0] == oracle.compute_likelihoods(bad_gop, oracle.LOGLESS)[0] != 0
     bad_qual = pack([("ACGT", [255, 30, 30, 30], [40] * 4, [40] * 4, [10] * 4)], ["ACGT"])
     assert oracle.simd_compute_likelihoods(bad_qual)[0] == oracle.compute_likelihoods(bad_qual, oracle.LOGLESS)[0] != 0
+
+
+def test_do_not_use_tristate_correction_closed_form(oracle):
+    """PairHMM.java:83-84 / Log10PairHMM.java:157: without the correction the mismatch prior of a Q30 base is 0.001,
+    so read "A" against haplotype "C" scores log10(0.001 * 0.9) instead of log10(0.001 / 3 * 0.9)."""
+    from gatk_amd.batch import pack
+    b = pack([("A", [30], [45], [45], [10])], ["A", "C"])
+    oracle.do_not_use_tristate_correction(True)
+    try:
+        for mode in (oracle.EXACT, oracle.ORIGINAL, oracle.LOGLESS):
+            rc, out = oracle.compute_likelihoods(b, mode)
+            assert rc == 0
+            np.testing.assert_allclose(out[0], [-0.0461920023, -3.0457574906], atol=2e-4 if mode == oracle.ORIGINAL else 1e-9)
+    finally:
+        oracle.do_not_use_tristate_correction(False)
+    rc, out = oracle.compute_likelihoods(b, oracle.LOGLESS)
+    np.testing.assert_allclose(out[0], [-0.0461920023, -3.5228787453], atol=1e-9)
