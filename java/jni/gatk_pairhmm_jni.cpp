@@ -10,6 +10,7 @@
 #if __has_include(<jni.h>)
 #include <jni.h>
 
+#include <string>
 #include <vector>
 
 #include "gatk_pairhmm.h"
@@ -49,9 +50,43 @@ bool flatten(JNIEnv* env, jobjectArray arrays, std::vector<uint8_t>& data, std::
 
 gatk_pairhmm* H(jlong h) { return reinterpret_cast<gatk_pairhmm*>(h); }
 
+// PairHMM.java:276-279: every per-read array must be as long as the read's bases.  The Java class checks this
+// too; a caller that reaches the native method some other way gets the same exception instead of misaligned bytes.
+bool same_lengths(JNIEnv* env, const std::vector<int32_t>& bases, const std::vector<int32_t>& other, const char* what) {
+    if (bases == other) return true;
+    const std::string msg = std::string("Read bases and ") + what + " aren't the same size";
+    env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), msg.c_str());
+    return false;
+}
+
 }  // namespace
 
 extern "C" {
+
+JNIEXPORT jint JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniDeviceCount(JNIEnv*, jclass) {
+    int32_t n = 0;
+    (void)gatk_pairhmm_device_count(&n);
+    return n;
+}
+
+JNIEXPORT jlong JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniCreateMulti(JNIEnv* env, jclass, jintArray devices) {
+    std::vector<int32_t> list;
+    if (devices) {
+        list.resize(static_cast<size_t>(env->GetArrayLength(devices)));
+        if (!list.empty()) env->GetIntArrayRegion(devices, 0, static_cast<jsize>(list.size()), reinterpret_cast<jint*>(list.data()));
+    }
+    gatk_pairhmm* h = nullptr;
+    if (const int rc = gatk_pairhmm_create_multi(list.empty() ? nullptr : list.data(), static_cast<int32_t>(list.size()), &h)) { throw_for(env, rc); return 0; }
+    return reinterpret_cast<jlong>(h);
+}
+
+JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniSetOption(JNIEnv* env, jclass, jlong h, jstring name, jdouble value) {
+    const char* n = env->GetStringUTFChars(name, nullptr);
+    if (!n) return;  // OutOfMemoryError is pending
+    const int rc = gatk_pairhmm_set_option(H(h), n, value);
+    env->ReleaseStringUTFChars(name, n);
+    if (rc) throw_for(env, rc);
+}
 
 JNIEXPORT jlong JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniCreate(JNIEnv* env, jclass, jint device) {
     gatk_pairhmm* h = nullptr;
@@ -69,12 +104,15 @@ JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPair
     JNIEnv* env, jclass, jlong h, jobjectArray readBases, jobjectArray readQuals, jobjectArray insGOP, jobjectArray delGOP,
     jobjectArray gcp, jobjectArray hapBases, jdoubleArray likelihoodArray) {
     std::vector<uint8_t> rb, rq, ri, rd, rg, hb;
-    std::vector<int32_t> ro, o2, ho;
-    if (!flatten(env, readBases, rb, ro) || !flatten(env, readQuals, rq, o2) || !flatten(env, insGOP, ri, o2) ||
-        !flatten(env, delGOP, rd, o2) || !flatten(env, gcp, rg, o2) || !flatten(env, hapBases, hb, ho)) {
+    std::vector<int32_t> ro, oq, oi, od, og, ho;
+    if (!flatten(env, readBases, rb, ro) || !flatten(env, readQuals, rq, oq) || !flatten(env, insGOP, ri, oi) ||
+        !flatten(env, delGOP, rd, od) || !flatten(env, gcp, rg, og) || !flatten(env, hapBases, hb, ho)) {
         env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "readBases cannot be null");
         return;
     }
+    if (!same_lengths(env, ro, oq, "read quals") || !same_lengths(env, ro, oi, "read insertion quals") ||
+        !same_lengths(env, ro, od, "read deletion quals") || !same_lengths(env, ro, og, "overall GCP"))
+        return;
     gatk_pairhmm_batch b{static_cast<int32_t>(ro.size()) - 1, static_cast<int32_t>(ho.size()) - 1, rb.data(), rq.data(), ri.data(),
                          rd.data(), rg.data(), ro.data(), hb.data(), ho.data()};
     std::vector<double> out(static_cast<size_t>(b.num_reads) * b.num_haps);

@@ -17,6 +17,7 @@ import org.broadinstitute.gatk.utils.sam.GATKSAMRecord;
 
 import java.util.List;
 import java.util.Map;
+import java.util.concurrent.atomic.AtomicInteger;
 
 public class HipLoglessPairHMM extends PairHMM {
 
@@ -27,10 +28,17 @@ public class HipLoglessPairHMM extends PairHMM {
     /** gatk_pairhmm* of include/gatk_pairhmm.h; 0 after close(). */
     private long handle;
 
+    /** Instances created without a device take the node's GPUs in turn: the reference creates one PairHMM per
+     *  NanoScheduler map thread (PairHMM.java:297), so -nct threads spread over all GPUs of the node. */
+    private static final AtomicInteger nextDevice = new AtomicInteger(0);
+
     // ---- natives: one per C-ABI entry point that the PairHMM life cycle needs -----------------
+    private static native int jniDeviceCount();                                         // gatk_pairhmm_device_count
     private static native long jniCreate(int device);                                   // gatk_pairhmm_create
+    private static native long jniCreateMulti(int[] devices);                           // gatk_pairhmm_create_multi (null: every GPU)
+    private static native void jniSetOption(long handle, String name, double value);    // gatk_pairhmm_set_option
     private static native void jniInitialize(long handle, int readMax, int hapMax);     // gatk_pairhmm_initialize
-    private static native void jniComputeLikelihoods(long handle,                       // gatk_pairhmm_compute_likelihoods_ptrs
+    private static native void jniComputeLikelihoods(long handle,                       // gatk_pairhmm_compute_likelihoods (the veneer concatenates the arrays)
                                                      byte[][] readBases, byte[][] readQuals,
                                                      byte[][] insertionGOP, byte[][] deletionGOP, byte[][] overallGCP,
                                                      byte[][] haplotypeBases, double[] likelihoodArray);
@@ -39,12 +47,26 @@ public class HipLoglessPairHMM extends PairHMM {
     private static native void jniFinalizeRegion(long handle);                          // gatk_pairhmm_finalize_region
     private static native void jniClose(long handle);                                   // gatk_pairhmm_close
 
+    /** One GPU per instance, the node's GPUs in turn. */
     public HipLoglessPairHMM() {
-        this(0);
+        this(nextDevice.getAndIncrement() % Math.max(1, jniDeviceCount()));
     }
 
     public HipLoglessPairHMM(final int device) {
         handle = jniCreate(device);  // throws IllegalStateException when no GPU is present: no CPU fallback
+    }
+
+    /** One instance over several GPUs (null: all of them): for a caller that hands over many regions per call
+     *  from one thread; the native side shards them and writes every region's likelihoods in place. */
+    public HipLoglessPairHMM(final int[] devices) {
+        handle = jniCreateMulti(devices);
+    }
+
+    /** PairHMM.java:83-84. */
+    @Override
+    protected void doNotUseTristateCorrection() {
+        super.doNotUseTristateCorrection();
+        jniSetOption(handle, "do_not_use_tristate_correction", 1.0);
     }
 
     @Override
