@@ -650,7 +650,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             const int o = b.hap_offsets[a], len = b.hap_offsets[a + 1] - o;
             hap_total += len;
             rp.hap_max = std::max(rp.hap_max, len);
-            if (!any_hap_other) scan_alphabet(b.hap_bases + o, len, any_hap_n, any_hap_other);
+            scan_alphabet(b.hap_bases + o, len, any_hap_n, any_hap_other);  // every haplotype: an 'N' must be seen wherever it is
         }
         int read_max = 0, read_min = std::numeric_limits<int>::max(), nonempty = 0;
         int64_t len_total = 0;

@@ -23,8 +23,8 @@
 //     registers;
 //   * the emission term prior[i][j] is either selected per cell by comparing bytes (any
 //     alphabet), or, when the haplotypes are made of A/C/G/T(/N) only, read from a per-wave LDS
-//     table [row][base code][lane] that the lane fills once per task: one conflict-free
-//     ds_read_b32 per cell replaces the compare + select pair on the vector ALU;
+//     table [row group][base code][lane][4 rows] that the lane fills once per task: one conflict-free
+//     ds_read_b128 per four cells replaces the compare + select pairs on the vector ALU;
 //   * lanes outside 1 <= column <= H are masked off, and every lane segment begins with a pad
 //     row that reproduces matrix row 0, so every pair starts from exact boundary values and no
 //     pair ever reads another pair's state.
@@ -104,11 +104,42 @@ __device__ __forceinline__ void pin(unsigned& x) { asm volatile("" : "+v"(x)); }
 
 constexpr bool is_lut(int mode) { return mode == kEmitLut4 || mode == kEmitLut5; }
 constexpr int lut_codes(int mode) { return mode == kEmitLut5 ? 5 : 4; }
-// The emission table keeps two read rows side by side, [row pair][base code][lane][2], so that one
-// ds_read_b64 (conflict-free: consecutive lanes, consecutive 8-byte slots) fetches two cells' terms.
-constexpr int lut_row_pairs(int k) { return (k + 1) / 2; }
-constexpr int kLutCodeStride = kWave * 8;  // bytes between two base codes of one row pair
+// The emission table keeps kLutRowsPerRead read rows side by side, [row group][base code][lane][rows], so that one
+// LDS read fetches several cells' terms.
+// Four rows side by side: one ds_read_b128 fetches four cells' terms (conflict-free: consecutive lanes, consecutive
+// 16-byte slots).  The same bytes as two ds_read_b64 in half the LDS instructions, which measured 3-4 % less
+// kernel time on a device that runs this kernel at its power cap.  -DPAIRHMM_LUT_PAIRS builds the two-row layout.
+#ifdef PAIRHMM_LUT_PAIRS
+constexpr int kLutRowsPerRead = 2;
+#else
+constexpr int kLutRowsPerRead = 4;
+#endif
+constexpr int lut_row_pairs(int k) { return (k + kLutRowsPerRead - 1) / kLutRowsPerRead; }
+constexpr int kLutCodeStride = kWave * 4 * kLutRowsPerRead;  // bytes between two base codes of one row pair
 constexpr int lut_table_bytes(int k, int mode) { return is_lut(mode) ? lut_row_pairs(k) * lut_codes(mode) * kLutCodeStride : 0; }
+// index, in floats, of the table entry of row r against base code c for this lane
+__device__ __forceinline__ int lut_index(const int r, const int c, const int codes, const int lane) {
+    return (((r / kLutRowsPerRead) * codes + c) * kWave + lane) * kLutRowsPerRead + (r % kLutRowsPerRead);
+}
+// the emission terms of the lane's K rows against the base code whose table offset is code_off
+template <typename T, int K, int CODES>
+__device__ __forceinline__ void lut_emit(const unsigned char* tbl_lane, const unsigned code_off, T (&prior)[K]) {
+#pragma unroll
+    for (int g = 0; g < lut_row_pairs(K); ++g) {
+        const unsigned char* p = tbl_lane + code_off + g * CODES * kLutCodeStride;
+#ifndef PAIRHMM_LUT_PAIRS
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        prior[4 * g] = v.x;
+        if (4 * g + 1 < K) prior[4 * g + 1] = v.y;
+        if (4 * g + 2 < K) prior[4 * g + 2] = v.z;
+        if (4 * g + 3 < K) prior[4 * g + 3] = v.w;
+#else
+        const float2 v = *reinterpret_cast<const float2*>(p);
+        prior[2 * g] = v.x;
+        if (2 * g + 1 < K) prior[2 * g + 1] = v.y;
+#endif
+    }
+}
 
 // Registers of one lane: K read rows.  Two arithmetic forms share the layout:
 //
@@ -358,7 +389,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
                 const unsigned letters[5] = {'A', 'C', 'T', 'G', 'N'};
 #pragma unroll
                 for (int c = 0; c < kCodes; ++c)
-                    tbl[(((r >> 1) * kCodes + c) * kWave + lane) * 2 + (r & 1)] = (XB[r] == letters[c] || c == 4) ? P[r] : Q[r];
+                    tbl[lut_index(r, c, kCodes, lane)] = (XB[r] == letters[c] || c == 4) ? P[r] : Q[r];
             } else {
                 pin(XB[r]); pin(P[r]); pin(Q[r]);
             }
@@ -436,15 +467,8 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     PHASE_END(1);
     if (kLut) {
         const uint16_t* hp = reinterpret_cast<const uint16_t*>(hap_img) + (kHapFrontPad - ld.seg_lane);
-        const unsigned char* tbl_lane = slice + lane * 8;
-        auto emit = [&](const unsigned code_off, T (&prior)[K]) {
-#pragma unroll
-            for (int g = 0; g < lut_row_pairs(K); ++g) {
-                const float2 v = *reinterpret_cast<const float2*>(tbl_lane + code_off + g * kCodes * kLutCodeStride);
-                prior[2 * g] = v.x;
-                if (2 * g + 1 < K) prior[2 * g + 1] = v.y;
-            }
-        };
+        const unsigned char* tbl_lane = slice + lane * 4 * kLutRowsPerRead;
+        auto emit = [&](const unsigned code_off, T (&prior)[K]) { lut_emit<T, K, kCodes>(tbl_lane, code_off, prior); };
         auto masked_step = [&](const int step) {
             const T Sin = shr1(w.Sout);
             const T Iin = shr1(w.Iout);
@@ -656,7 +680,7 @@ __device__ __forceinline__ void run_stream(const DeviceBatch& B, const int task_
             w.Ml[r] = 0.0f; w.El[r] = 0.0f; w.Sd[r] = 0.0f;
 #pragma unroll
             for (int c = 0; c < kCodes; ++c)
-                tbl[(((r >> 1) * kCodes + c) * kWave + lane) * 2 + (r & 1)] = (xb == letters[c] || c == 4) ? P : Q;
+                tbl[lut_index(r, c, kCodes, lane)] = (xb == letters[c] || c == 4) ? P : Q;
         }
         w.Sout = 0.0f; w.Iout = 0.0f;
     }
@@ -669,15 +693,8 @@ __device__ __forceinline__ void run_stream(const DeviceBatch& B, const int task_
     // ---- sweep -----------------------------------------------------------------------------------------
     const int t = ld.seg_lane;
     const uint16_t* const hp = B.hap_stream + run_base - t;  // hp[s]: table offset of this lane's position at step s
-    const unsigned char* const tbl_lane = slice + lane * 8;
-    auto emit = [&](const unsigned code_off, T (&prior)[K]) {
-#pragma unroll
-        for (int g = 0; g < lut_row_pairs(K); ++g) {
-            const float2 v = *reinterpret_cast<const float2*>(tbl_lane + code_off + g * kCodes * kLutCodeStride);
-            prior[2 * g] = v.x;
-            if (2 * g + 1 < K) prior[2 * g + 1] = v.y;
-        }
-    };
+    const unsigned char* const tbl_lane = slice + lane * 4 * kLutRowsPerRead;
+    auto emit = [&](const unsigned code_off, T (&prior)[K]) { lut_emit<T, K, kCodes>(tbl_lane, code_off, prior); };
     auto emit4 = [&](const uint2 codes, T (&prior)[4][K]) {
         emit(codes.x & 0xffffu, prior[0]);
         emit(codes.x >> 16, prior[1]);
