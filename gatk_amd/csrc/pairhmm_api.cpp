@@ -36,7 +36,7 @@ int lds_bytes_per_wave(int rows_per_lane, int emit_mode, int max_hap_len);
 int stream_lds_bytes_per_wave(int rows_per_lane, int emit_mode);
 hipError_t launch_stream(const DeviceBatch& B, int rows_per_lane, int emit_mode, hipStream_t stream);
 hipError_t launch_finish_stream(const DeviceBatch& B, hipStream_t stream);
-hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int blocks, hipStream_t stream);
+hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int waves, hipStream_t stream);
 hipError_t launch_normalize_reads(const DeviceBatch& B, const int32_t* reference_allele_index, int best_to_zero, double cap, hipStream_t stream);
 hipError_t launch_flag_poorly_modelled_reads(const DeviceBatch& B, double maximum_error_per_base, uint8_t* flags, hipStream_t stream);
 hipError_t launch_marginalize_reads(const DeviceBatch& B, const int32_t* old_to_new, const int64_t* new_base, const int32_t* new_count,
@@ -1100,7 +1100,7 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
                 L.pair_list = B.pair_lists + bk.pair_begin;
                 L.slot_lanes = bk.slot_lanes;
                 const int64_t waves = (bk.num_pairs + kWave / bk.slot_lanes - 1) / (kWave / bk.slot_lanes);
-                HIP_TRY(launch_pairs(L, bk.pair_rows_per_lane, static_cast<int>(std::min<int64_t>((waves + kWavesPerBlock - 1) / kWavesPerBlock, 2048)), s));
+                HIP_TRY(launch_pairs(L, bk.pair_rows_per_lane, static_cast<int>(std::min<int64_t>(waves, 8192)), s));
                 continue;
             }
             const int blocks = std::min((bk.num_tasks + kWavesPerBlock - 1) / kWavesPerBlock, 1024);

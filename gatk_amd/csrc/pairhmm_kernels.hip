@@ -858,12 +858,20 @@ __global__ void __launch_bounds__(256) finish_stream(const DeviceBatch B) {
 // ---------------------------------------------------------------------------------------------
 // fp64 pair pass
 // ---------------------------------------------------------------------------------------------
-// Scores the queued (read, haplotype) pairs in double, plain arithmetic form.  A wave takes
-// 64 / slot_lanes consecutive pairs of the list, whatever reads and haplotypes they are: every pair
-// gets slot_lanes lanes, and each lane follows its own haplotype through the code stream.  Only the
-// pairs that need it are recomputed, however they were grouped in the fp32 pass.
+// Scores the queued (read, haplotype) pairs in double, plain arithmetic form (the reference's own operations in
+// linear space, so that results and the point of underflow to zero are those of a double-precision
+// LoglessPairHMM with the 2^1020 initial condition).  A wave takes 64 / slot_lanes consecutive pairs of the
+// list, whatever reads and haplotypes they are: every pair gets slot_lanes lanes, and each lane follows its own
+// haplotype through the code stream.  Only the pairs that need it are recomputed, however they were grouped in
+// the fp32 pass.  The emission terms come from a per-wave LDS table of doubles [row pair][base code][lane][2]
+// read with one ds_read_b128 per two cells, one step ahead of their use.  A base code's table offset is the one
+// the haplotype stream holds (64 lanes x 16 bytes = kLutCodeStride), so the codes need no conversion.
+constexpr int kPairCodes = 5;  // A, C, T, G, N: the pass does not know which letters its haplotypes use
+static_assert(kLutCodeStride == kWave * 16, "the pair pass reads the stream's table offsets as offsets into a table of double pairs");
+constexpr int pair_table_bytes(int k) { return ((k + 1) / 2) * kPairCodes * kLutCodeStride; }
+
 template <int K>
-__device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_pair, const int num_pairs, const int lane) {
+__device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_pair, const int num_pairs, unsigned char* slice, const int lane) {
     using T = double;
     const int slot = lane / B.slot_lanes;
     const int t = lane - slot * B.slot_lanes;
@@ -880,17 +888,17 @@ __device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_
     const int H = used ? B.hap_len[hap] : 0;
     const uint16_t* const hp = B.hap_stream + (used ? B.hap_stream_off[hap] : kStreamFrontPad) - t;  // hp[s]: code of column s - t (0-based)
 
-    // per-row constants straight from the quality bytes (as the one-haplotype fp64 pass does)
+    // per-row constants straight from the quality bytes (as the one-haplotype fp64 pass does), and the emission table
     Rows<T, K> w;
-    unsigned XC[K];  // table offset of the read base's code; one that no haplotype entry holds for other letters
-    T P[K], Q[K];
     const T initD = static_cast<T>(::ldexp(1.0, Scale<T>::kExp2) / static_cast<double>(H > 0 ? H : 1));
+    double* const tbl = reinterpret_cast<double*>(slice);
+    const unsigned letters[kPairCodes] = {'A', 'C', 'T', 'G', 'N'};
 #pragma unroll
     for (int r = 0; r < K; ++r) {
         const int i = first_row + r;
         double p = 0, q = 0, t4 = 0, t5 = 0, t0n = 0, t1n = 0, t2n = 0, t3n = 0;
         bool pad = false, has_next = false;
-        unsigned xc = 0xffffu;
+        unsigned xb = kNoBase;
         const bool sum_row = used && i == R + 1;
         const bool last_row = used && i == R;
         if (sum_row) {
@@ -900,7 +908,7 @@ __device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_
             if (i >= 1) {
                 const unsigned x = B.read_bases[ro + i - 1];
                 const double e = B.err_prob[effective_qual(B, ro + i - 1, pr.read_idx)];
-                xc = (x == 'A' ? 0u : x == 'C' ? 1u : x == 'T' ? 2u : x == 'G' ? 3u : 0x7fu) * kLutCodeStride;
+                xb = x;
                 p = 1.0 - e;
                 q = (x == 'N') ? p : e / B.mismatch_divisor;
                 t4 = B.err_prob[B.del_gop[ro + i - 1] & 127u];
@@ -922,8 +930,6 @@ __device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_
             }
         }
         const bool real_next = has_next && i >= 1;
-        XC[r] = xc;
-        P[r] = p; Q[r] = q;
         w.T5[r] = t5;
         w.A[r] = real_next ? t0n : last_row ? 1.0 : 0.0;
         w.B[r] = last_row ? 1.0 : t1n;
@@ -931,9 +937,11 @@ __device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_
         w.D[r] = real_next ? t3n : 0.0;
         w.E[r] = t4 * t1n;
         pin(w.A[r]); pin(w.B[r]); pin(w.C[r]); pin(w.D[r]); pin(w.E[r]); pin(w.T5[r]);
-        pin(XC[r]); pin(P[r]); pin(Q[r]);
         w.Ml[r] = 0.0;
         w.El[r] = pad ? initD : 0.0;  // column 0
+#pragma unroll
+        for (int cd = 0; cd < kPairCodes; ++cd)  // a haplotype 'N' matches every row, a read 'N' (q = p) every column
+            tbl[(((r >> 1) * kPairCodes + cd) * kWave + lane) * 2 + (r & 1)] = (xb == letters[cd] || cd == 4) ? p : q;
     }
 #pragma unroll
     for (int r = 1; r < K; ++r) w.Sd[r] = w.El[r - 1] * w.E[r - 1];
@@ -947,24 +955,33 @@ __device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) hmax = max(hmax, __shfl_xor(hmax, d));
     const int steps = hmax + B.slot_lanes - 1;
-    const unsigned n_code = 4u * kLutCodeStride;
+    const unsigned char* const tbl_lane = slice + lane * 16;
+    auto emit = [&](const unsigned code_off, T (&prior)[K]) {
+#pragma unroll
+        for (int g = 0; g < (K + 1) / 2; ++g) {
+            const double2 v = *reinterpret_cast<const double2*>(tbl_lane + code_off + g * kPairCodes * kLutCodeStride);
+            prior[2 * g] = v.x;
+            if (2 * g + 1 < K) prior[2 * g + 1] = v.y;
+        }
+    };
     // a lane whose haplotype is shorter than the wave's longest stops reading the stream behind its own
     const int last_block = H + t + 8;
     uint2 codes = load_codes(hp);
     uint2 next_codes = load_codes(hp + 4);
+    T pn[K];  // emission terms one step ahead of their use
+    emit(codes.x & 0xffffu, pn);
     for (int s0 = 0; s0 < steps; s0 += 4) {
         const uint2 after = load_codes(hp + min(s0 + 8, last_block));
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const T Sin = shr1(w.Sout);
             const T Iin = shr1(w.Iout);
-            const unsigned y = u == 0 ? (codes.x & 0xffffu) : u == 1 ? (codes.x >> 16) : u == 2 ? (codes.y & 0xffffu) : (codes.y >> 16);
-            if (static_cast<unsigned>(s0 + u - t) < static_cast<unsigned>(H)) {
-                T prior[K];
+            T pc[K];
 #pragma unroll
-                for (int r = 0; r < K; ++r) prior[r] = (y == XC[r] || y == n_code) ? P[r] : Q[r];
-                column<T, K>(w, prior, Sin, Iin);
-            }
+            for (int r = 0; r < K; ++r) pc[r] = pn[r];
+            const unsigned y_next = u == 0 ? (codes.x >> 16) : u == 1 ? (codes.y & 0xffffu) : u == 2 ? (codes.y >> 16) : (next_codes.x & 0xffffu);
+            emit(y_next, pn);
+            if (static_cast<unsigned>(s0 + u - t) < static_cast<unsigned>(H)) column<T, K>(w, pc, Sin, Iin);
         }
         codes = next_codes;
         next_codes = after;
@@ -975,15 +992,16 @@ __device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_
     }
 }
 
+// One wave per block: a wave's table of doubles is up to 40 KiB (16 rows per lane).
 template <int K>
-__global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_pairs(const DeviceBatch B) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & (kWave - 1);
+__global__ void __launch_bounds__(kWave) fwd_pairs(const DeviceBatch B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x;
     const int n = *B.pair_count;
     const int per_wave = kWave / B.slot_lanes;
-    const int stride = gridDim.x * kWavesPerBlock * per_wave;
-    for (int first = (blockIdx.x * kWavesPerBlock + wave) * per_wave; first < n; first += stride) {
-        run_pairs<K>(B, first, min(per_wave, n - first), lane);
+    const int stride = gridDim.x * per_wave;
+    for (int first = blockIdx.x * per_wave; first < n; first += stride) {
+        run_pairs<K>(B, first, min(per_wave, n - first), lds, lane);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -1218,12 +1236,13 @@ hipError_t launch_stream(const DeviceBatch& B, int rows_per_lane, int emit_mode,
     }
 }
 
-// Enqueue the fp64 pair pass of one bucket (B.pair_count / pair_list / slot_lanes set for it).
-hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int blocks, hipStream_t stream) {
-    if (blocks <= 0) return hipSuccess;
-    const dim3 grid(blocks), block(kWave * kWavesPerBlock);
+// Enqueue the fp64 pair pass of one bucket (B.pair_count / pair_list / slot_lanes set for it); waves: one-wave blocks.
+hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int waves, hipStream_t stream) {
+    if (waves <= 0) return hipSuccess;
+    const dim3 grid(waves), block(kWave);
+    const size_t lds = static_cast<size_t>(pair_table_bytes(rows_per_lane));
     switch (rows_per_lane) {
-#define PAIRHMM_PAIRS_CASE(k) case k: hipLaunchKernelGGL((fwd_pairs<k>), grid, block, 0, stream, B); break;
+#define PAIRHMM_PAIRS_CASE(k) case k: hipLaunchKernelGGL((fwd_pairs<k>), grid, block, lds, stream, B); break;
         PAIRHMM_PAIRS_CASE(1) PAIRHMM_PAIRS_CASE(2) PAIRHMM_PAIRS_CASE(3) PAIRHMM_PAIRS_CASE(4) PAIRHMM_PAIRS_CASE(5)
         PAIRHMM_PAIRS_CASE(6) PAIRHMM_PAIRS_CASE(7) PAIRHMM_PAIRS_CASE(8) PAIRHMM_PAIRS_CASE(9) PAIRHMM_PAIRS_CASE(10)
         PAIRHMM_PAIRS_CASE(11) PAIRHMM_PAIRS_CASE(12) PAIRHMM_PAIRS_CASE(14) PAIRHMM_PAIRS_CASE(16)
