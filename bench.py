@@ -38,8 +38,9 @@ FLOP_PER_CELL = 12          # 8 mul + 4 add of the linear-space three-state recu
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X: 256 CU x 4 SIMD x 32 lanes x 2 FLOP x 2.4 GHz
 # HBM bytes of one fp32 forward launch on the default workload, from PMC counters collected in a run
 # of their own (2 x FETCH_SIZE + WRITE_SIZE); not measured live
-PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD = 2 * 10287.9e3 + 6858.8e3
-PMC_TRAFFIC_SOURCE = "profiles/r01_pmc_stream_kernel.txt (separate --pmc passes of this command; not measured in this run)"
+# (FETCH_SIZE counts a wide coalesced read at half its bytes on gfx950: doubled; both counters are in KiB)
+PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD = (2 * 10283.2 + 6408.1) * 1024
+PMC_TRAFFIC_SOURCE = "profiles/r02_pmc_stream_kernel.txt (separate rocprofv3 --pmc passes over tools/prof_run.py 4096 4; not measured in this run)"
 EMIT_MODES = {0: "compare", 1: "compare+N", 2: "table", 3: "table+N"}
 
 
@@ -204,6 +205,8 @@ def main():
     ap.add_argument("--haps", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the other workloads (profiling runs)")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the host-pointer leg (profiling runs: its calls are cut into parts, whose smaller launches of the same kernel would mix into the kernel's average)")
     args = ap.parse_args()
 
     # stdout carries the one JSON line and nothing else: whatever libraries print while they set up (gloo announces
@@ -291,19 +294,21 @@ def main():
     hmm.close()
 
     # ---- end-to-end leg: host arrays in, host arrays out, on a handle with the default options ------------------
-    hmm = HipLoglessPairHMM(local_rank)
-    call = HostCall(hmm, [batch], True)
-    for _ in range(args.warmup):
-        call()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        call()
-    barrier()
-    e2e = max_over_ranks(time.perf_counter() - t0)
-    call.check()
-    assert float(np.abs(call.outs[0] - out).max()) <= 1e-5  # the two legs score the same batch
-    hmm.close()
+    e2e = None
+    if not args.no_end_to_end:
+        hmm = HipLoglessPairHMM(local_rank)
+        call = HostCall(hmm, [batch], True)
+        for _ in range(args.warmup):
+            call()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            call()
+        barrier()
+        e2e = max_over_ranks(time.perf_counter() - t0)
+        call.check()
+        assert float(np.abs(call.outs[0] - out).max()) <= 1e-5  # the two legs score the same batch
+        hmm.close()
 
     # ---- N > 1: the whole-genome-shaped workload, sharded over the ranks, host gather inside the clock ---------
     c4 = None
@@ -367,8 +372,9 @@ def main():
                        "value_is": "resident pass: the batch is in HBM when the clock starts; every kernel of a pass is inside it",
                        "parallelism": f"independent batches on {world} GPU(s), host gather, no collective"},
             "resident_gcups": round(total_cells * steps / elapsed / 1e9, 2),
-            "end_to_end": {"gcups": round(total_cells * steps / e2e / 1e9, 2), "ms_per_call": round(e2e / steps * 1e3, 4), "calls_timed": args.steps,
-                           "path": "gatk_pairhmm_compute_likelihoods on host arrays: checks + planning + H2D + kernels + fp64 reruns + D2H"},
+            "end_to_end": None if e2e is None else {
+                "gcups": round(total_cells * steps / e2e / 1e9, 2), "ms_per_call": round(e2e / steps * 1e3, 4), "calls_timed": args.steps,
+                "path": "gatk_pairhmm_compute_likelihoods on host arrays: checks + planning + H2D + kernels + fp64 reruns + D2H"},
             "roofline": {"bound": "valu", "bound_detail": "fp32 vector ALU (a recurrence: neither HBM- nor MFMA-bound)",
                          "kernel": kernel, "achieved": round(achieved, 2), "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
