@@ -1625,8 +1625,9 @@ namespace {
 // thread, PairHMM.java:297), do not fill the device one at a time and do not overlap well either.  With the
 // handle option "combine_calls" such calls meet here: whichever caller finds an engine free takes every
 // request that is waiting on the device, its own included, through one gatk_pairhmm_compute_regions pass on
-// that engine and hands the results out; callers that arrive meanwhile wait for the next pass.  Two engines
-// per device, so that one pass is planned while another runs.  They live until the process ends.
+// that engine and hands the results out; callers that arrive meanwhile wait for the next pass.  Three engines
+// per device, so that passes are planned and fetched while another runs.  They are released when the last caller's
+// handle closes.
 struct Combiner {
     struct Request {
         const gatk_pairhmm_batch* batch;
@@ -1635,13 +1636,16 @@ struct Combiner {
         std::string error;
         bool taken = false, done = false;
     };
-    static constexpr int kEngines = 2;
+    static constexpr int kEngines = 3;
+    static constexpr int kLingerMicroseconds = 10;  // a leader that finds fewer than kLingerBelow requests waits this long for more,
+    static constexpr size_t kLingerBelow = 8;       // while another engine keeps the device busy
     static constexpr size_t kMaxRequestsPerPass = 64;
     std::mutex m;
     std::condition_variable cv;
     std::deque<Request*> pending;
     gatk_pairhmm* engine[kEngines] = {};
     bool busy[kEngines] = {};
+    std::atomic<uint64_t> passes_ended{0};  // changed under the mutex; waiting callers spin on it before they sleep
 };
 
 std::mutex g_combiners_mutex;
@@ -1694,9 +1698,32 @@ int compute_combined(int device, bool squash, const gatk_pairhmm_batch* batch, d
         if (!mine.taken)
             for (int k = 0; k < Combiner::kEngines && e < 0; ++k)
                 if (!c->busy[k]) e = k;
-        if (e < 0) { c->cv.wait(lock); continue; }
+        if (e < 0) {
+            // A pass takes about a hundred microseconds and a sleeping thread tens of microseconds to wake up:
+            // wait for the end of a pass by spinning first, and sleep only when that takes long.
+            const uint64_t seen = c->passes_ended.load(std::memory_order_acquire);
+            lock.unlock();
+            const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(250);
+            for (int k = 0; c->passes_ended.load(std::memory_order_acquire) == seen; ++k) {
+                _mm_pause();
+                if ((k & 63) == 63 && std::chrono::steady_clock::now() >= spin_until) break;
+            }
+            lock.lock();
+            if (c->passes_ended.load(std::memory_order_acquire) == seen) c->cv.wait(lock);  // the counter changes under this mutex
+            continue;
+        }
         // lead a pass on engine e
         c->busy[e] = true;
+        {   // a larger pass costs the device much less per region: give the other callers a moment to arrive
+            bool other_busy = false;
+            for (int k = 0; k < Combiner::kEngines; ++k) other_busy |= k != e && c->busy[k];
+            if (other_busy && c->pending.size() < Combiner::kLingerBelow) {
+                lock.unlock();
+                const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(Combiner::kLingerMicroseconds);
+                while (std::chrono::steady_clock::now() < until) _mm_pause();
+                lock.lock();
+            }
+        }
         std::vector<Combiner::Request*> reqs;
         while (!c->pending.empty() && reqs.size() < Combiner::kMaxRequestsPerPass) {
             reqs.push_back(c->pending.front());
@@ -1723,6 +1750,7 @@ int compute_combined(int device, bool squash, const gatk_pairhmm_batch* batch, d
             r->done = true;
         }
         c->busy[e] = false;
+        c->passes_ended.fetch_add(1, std::memory_order_release);
         c->cv.notify_all();
     }
     lock.unlock();

@@ -200,7 +200,7 @@ int gatk_pairhmm_device_count(int32_t* count);
  *                         larger one chooses the value per wave-group.
  *   "combine_calls"       default 0; 1 = gatk_pairhmm_compute_likelihoods calls too small to fill the device,
  *                         made at the same time by several threads on their own handles, are scored together:
- *                         a caller that finds one of the device's two shared engines free takes every waiting
+ *                         a caller that finds one of the device's three shared engines free takes every waiting
  *                         call through one device pass, its own included, the others wait for their results;
  *                         same results and exceptions, per caller; only on handles whose other options are
  *                         the defaults, squash_base_quals aside.
