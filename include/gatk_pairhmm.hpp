@@ -52,6 +52,12 @@ private:
 class HipLoglessPairHMM {
 public:
     explicit HipLoglessPairHMM(int device = 0) { check(gatk_pairhmm_create(device, &h_)); }
+    // One instance over several GPUs of the node (an empty list: every visible device): gatk_pairhmm_create_multi.
+    explicit HipLoglessPairHMM(const std::vector<int32_t>& devices) {
+        check(gatk_pairhmm_create_multi(devices.empty() ? nullptr : devices.data(), static_cast<int32_t>(devices.size()), &h_));
+    }
+    // PairHMM.doNotUseTristateCorrection(), PairHMM.java:83-84
+    void doNotUseTristateCorrection() { check(gatk_pairhmm_set_option(h_, "do_not_use_tristate_correction", 1.0)); }
     ~HipLoglessPairHMM() { close(); }
     HipLoglessPairHMM(const HipLoglessPairHMM&) = delete;
     HipLoglessPairHMM& operator=(const HipLoglessPairHMM&) = delete;
