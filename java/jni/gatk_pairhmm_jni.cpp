@@ -143,5 +143,140 @@ JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPair
     gatk_pairhmm_close(H(h));
 }
 
+// ---- HipResidentReadLikelihoods: the ReadLikelihoods steps on results that stay on the device ------------------------
+
+namespace {
+
+// One region per sample: the sample's reads against the collection's alleles.
+struct ResidentRegions {
+    gatk_pairhmm* handle = nullptr;
+    gatk_pairhmm_resident* resident = nullptr;
+    struct Sample {
+        std::vector<uint8_t> rb, rq, ri, rd, rg, hb;
+        std::vector<int32_t> ro, ho;
+    };
+    std::vector<Sample> samples;
+    std::vector<gatk_pairhmm_batch> batches() const {
+        std::vector<gatk_pairhmm_batch> b;
+        for (const Sample& s : samples)
+            b.push_back(gatk_pairhmm_batch{static_cast<int32_t>(s.ro.size()) - 1, static_cast<int32_t>(s.ho.size()) - 1, s.rb.data(), s.rq.data(),
+                                           s.ri.data(), s.rd.data(), s.rg.data(), s.ro.data(), s.hb.data(), s.ho.data(), nullptr});
+        return b;
+    }
+    int64_t pairs(size_t k) const { return (static_cast<int64_t>(samples[k].ro.size()) - 1) * (static_cast<int64_t>(samples[k].ho.size()) - 1); }
+    int64_t reads(size_t k) const { return static_cast<int64_t>(samples[k].ro.size()) - 1; }
+};
+
+ResidentRegions* RR(jlong p) { return reinterpret_cast<ResidentRegions*>(p); }
+
+jobjectArray to_double_arrays(JNIEnv* env, const std::vector<std::vector<double>>& v) {
+    jobjectArray out = env->NewObjectArray(static_cast<jsize>(v.size()), env->FindClass("[D"), nullptr);
+    for (size_t k = 0; out && k < v.size(); ++k) {
+        jdoubleArray a = env->NewDoubleArray(static_cast<jsize>(v[k].size()));
+        if (!a) return nullptr;
+        if (!v[k].empty()) env->SetDoubleArrayRegion(a, 0, static_cast<jsize>(v[k].size()), v[k].data());
+        env->SetObjectArrayElement(out, static_cast<jsize>(k), a);
+        env->DeleteLocalRef(a);
+    }
+    return out;
+}
+
+}  // namespace
+
+JNIEXPORT jlong JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipResidentReadLikelihoods_jniResidentOpen(JNIEnv*, jclass, jlong h) {
+    ResidentRegions* r = new ResidentRegions();
+    r->handle = H(h);
+    return reinterpret_cast<jlong>(r);
+}
+
+JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipResidentReadLikelihoods_jniResidentAddSample(
+    JNIEnv* env, jclass, jlong p, jobjectArray readBases, jobjectArray readQuals, jobjectArray insGOP, jobjectArray delGOP, jobjectArray gcp,
+    jobjectArray hapBases) {
+    ResidentRegions::Sample s;
+    std::vector<int32_t> oq, oi, od, og;
+    if (!flatten(env, readBases, s.rb, s.ro) || !flatten(env, readQuals, s.rq, oq) || !flatten(env, insGOP, s.ri, oi) ||
+        !flatten(env, delGOP, s.rd, od) || !flatten(env, gcp, s.rg, og) || !flatten(env, hapBases, s.hb, s.ho)) {
+        env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "readBases cannot be null");
+        return;
+    }
+    if (!same_lengths(env, s.ro, oq, "read quals") || !same_lengths(env, s.ro, oi, "read insertion quals") ||
+        !same_lengths(env, s.ro, od, "read deletion quals") || !same_lengths(env, s.ro, og, "overall GCP"))
+        return;
+    RR(p)->samples.push_back(std::move(s));
+}
+
+JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipResidentReadLikelihoods_jniResidentCompute(JNIEnv* env, jclass, jlong p) {
+    ResidentRegions* r = RR(p);
+    const std::vector<gatk_pairhmm_batch> b = r->batches();
+    int rc = gatk_pairhmm_upload(r->handle, static_cast<int32_t>(b.size()), b.data(), &r->resident);
+    if (rc == GATK_PAIRHMM_OK) rc = gatk_pairhmm_compute_resident(r->handle, r->resident, 1);
+    if (rc) throw_for(env, rc);
+}
+
+JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipResidentReadLikelihoods_jniResidentNormalize(
+    JNIEnv* env, jclass, jlong p, jint referenceAlleleIndex, jboolean bestToZero, jdouble cap) {
+    ResidentRegions* r = RR(p);
+    const std::vector<int32_t> ref(r->samples.size(), referenceAlleleIndex);  // the samples share the collection's alleles
+    if (const int rc = gatk_pairhmm_normalize_resident(r->handle, r->resident, ref.data(), bestToZero ? 1 : 0, cap)) throw_for(env, rc);
+}
+
+JNIEXPORT jobjectArray JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipResidentReadLikelihoods_jniResidentPoorlyModeled(
+    JNIEnv* env, jclass, jlong p, jdouble maxErrorPerBase) {
+    ResidentRegions* r = RR(p);
+    std::vector<std::vector<uint8_t>> flags(r->samples.size());
+    std::vector<uint8_t*> ptrs;
+    for (size_t k = 0; k < flags.size(); ++k) { flags[k].assign(static_cast<size_t>(r->reads(k)) + 1, 0); ptrs.push_back(flags[k].data()); }
+    if (const int rc = gatk_pairhmm_poorly_modeled_resident(r->handle, r->resident, maxErrorPerBase, ptrs.data())) { throw_for(env, rc); return nullptr; }
+    jobjectArray out = env->NewObjectArray(static_cast<jsize>(flags.size()), env->FindClass("[B"), nullptr);
+    for (size_t k = 0; out && k < flags.size(); ++k) {
+        jbyteArray a = env->NewByteArray(static_cast<jsize>(r->reads(k)));
+        if (!a) return nullptr;
+        if (r->reads(k) > 0) env->SetByteArrayRegion(a, 0, static_cast<jsize>(r->reads(k)), reinterpret_cast<const jbyte*>(flags[k].data()));
+        env->SetObjectArrayElement(out, static_cast<jsize>(k), a);
+        env->DeleteLocalRef(a);
+    }
+    return out;
+}
+
+JNIEXPORT jobjectArray JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipResidentReadLikelihoods_jniResidentMarginalize(
+    JNIEnv* env, jclass, jlong p, jintArray oldToNew, jint newAlleleCount) {
+    ResidentRegions* r = RR(p);
+    std::vector<int32_t> map(static_cast<size_t>(env->GetArrayLength(oldToNew)) + 1);
+    env->GetIntArrayRegion(oldToNew, 0, static_cast<jsize>(map.size()) - 1, reinterpret_cast<jint*>(map.data()));
+    std::vector<std::vector<double>> outs(r->samples.size());
+    std::vector<const int32_t*> maps(r->samples.size(), map.data());
+    std::vector<int32_t> counts(r->samples.size(), newAlleleCount);
+    std::vector<double*> ptrs;
+    for (size_t k = 0; k < outs.size(); ++k) {
+        if (static_cast<size_t>(env->GetArrayLength(oldToNew)) != r->samples[k].ho.size() - 1) {
+            env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "the allele index map must have one entry per allele");
+            return nullptr;
+        }
+        outs[k].assign(static_cast<size_t>(r->reads(k)) * static_cast<size_t>(newAlleleCount), 0.0);
+        ptrs.push_back(outs[k].empty() ? nullptr : outs[k].data());
+    }
+    if (const int rc = gatk_pairhmm_marginalize_resident(r->handle, r->resident, maps.data(), counts.data(), ptrs.data())) { throw_for(env, rc); return nullptr; }
+    return to_double_arrays(env, outs);
+}
+
+JNIEXPORT jobjectArray JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipResidentReadLikelihoods_jniResidentFetch(JNIEnv* env, jclass, jlong p) {
+    ResidentRegions* r = RR(p);
+    std::vector<std::vector<double>> outs(r->samples.size());
+    std::vector<double*> ptrs;
+    for (size_t k = 0; k < outs.size(); ++k) {
+        outs[k].assign(static_cast<size_t>(r->pairs(k)), 0.0);
+        ptrs.push_back(outs[k].empty() ? nullptr : outs[k].data());
+    }
+    if (const int rc = gatk_pairhmm_download(r->handle, r->resident, ptrs.data())) { throw_for(env, rc); return nullptr; }
+    return to_double_arrays(env, outs);
+}
+
+JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipResidentReadLikelihoods_jniResidentClose(JNIEnv*, jclass, jlong p) {
+    ResidentRegions* r = RR(p);
+    if (!r) return;
+    if (r->resident) gatk_pairhmm_resident_free(r->handle, r->resident);
+    delete r;
+}
+
 }  // extern "C"
 #endif  // __has_include(<jni.h>)

@@ -62,6 +62,11 @@ public class HipLoglessPairHMM extends PairHMM {
         handle = jniCreateMulti(devices);
     }
 
+    /** The native gatk_pairhmm* of this instance, for HipResidentReadLikelihoods. */
+    long nativeHandle() {
+        return handle;
+    }
+
     /** PairHMM.java:83-84. */
     @Override
     protected void doNotUseTristateCorrection() {

@@ -1,6 +1,6 @@
 // Exercises the C++ host mirrors (include/gatk_pairhmm.hpp, include/gatk_smithwaterman.hpp) end to end on
 // GPU 0: the closed-form single-base answers, the read-major array, an error path, the BatchPairHMM
-// interface, the ReadLikelihoods steps on resident results and three Smith-Waterman cases.
+// interface, the ReadLikelihoods steps on resident results, three Smith-Waterman cases and a multi-device instance.
 // Prints "cxx_driver ok" and exits 0 when everything matches.
 #include <cmath>
 #include <cstdio>
@@ -60,6 +60,15 @@ int main() {
             if (over.getCigar() != "2I8M2I") { std::printf("SW overhang case: %s\n", over.getCigar().c_str()); return 1; }
         }
         hmm.close();
+        {
+            // one instance over two engines (device 0 listed twice), without the tristate correction:
+            // read A (Q30) against haplotype C scores log10(0.001 * 0.9)
+            gatk::HipLoglessPairHMM multi(std::vector<int32_t>{0, 0});
+            multi.doNotUseTristateCorrection();
+            gatk::LikelihoodMatrix m3({B("A"), B("C")}, 1);
+            multi.computeLikelihoods(m3, {{B("A"), {30}, {45}, {45}}}, {{10}});
+            if (std::fabs(m3.get(0, 0) - want[0]) > 1e-6 || std::fabs(m3.get(1, 0) - (-3.0457574906)) > 1e-6) { std::printf("multi-device / tristate mismatch: %.10f\n", m3.get(1, 0)); return 1; }
+        }
     } catch (const std::exception& e) {
         std::printf("exception: %s\n", e.what());
         return 2;
