@@ -291,7 +291,7 @@ struct gatk_pairhmm {
     int device = 0;
     hipStream_t stream = nullptr;
     int wave_slots = 3072;  // waves the device holds at once at three per SIMD
-    size_t kernel_upload_bytes = size_t{256} << 10;  // uploads up to this size are copied by a kernel, not by the DMA engine
+    size_t kernel_upload_bytes = size_t{1} << 20;  // uploads up to this size are copied by a kernel, not by the DMA engine
     int64_t per_group_factor = 32;  // calls with at least this many pairs per wave slot choose rows per lane per wave-group
     bool combine_calls = false;  // small compute_likelihoods calls of all threads on this device share device passes
     bool pipeline_ramp = true;  // the first two parts of a cut call are a quarter and a half of pipeline_pairs

@@ -204,7 +204,7 @@ int gatk_pairhmm_device_count(int32_t* count);
  *                         call through one device pass, its own included, the others wait for their results;
  *                         same results and exceptions, per caller; only on handles whose other options are
  *                         the defaults, squash_base_quals aside.
- *   "kernel_upload_bytes" default 262144: an upload of at most that many bytes is copied out of the pinned
+ *   "kernel_upload_bytes" default 1048576: an upload of at most that many bytes is copied out of the pinned
  *                         staging buffer by a kernel on the compute stream instead of by the DMA engine, whose
  *                         hand-over to the first kernel costs more than the copy of a region-sized call.
  *   "wave_slots"          waves the planner assumes the device holds at once, default 12 per CU (occupancy
