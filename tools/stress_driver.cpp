@@ -4,11 +4,14 @@
 // reads that underflow fp32) through every entry point and checks that differently planned engine
 // configurations agree: automatic planning against forced rows per lane with one haplotype per work item,
 // one big call against region-at-a-time calls and against calls of a few dozen regions on a default handle,
-// host-pointer calls against the resident path.
+// host-pointer calls against the resident path, a multi-device handle (three engines on GPU 0) against one engine
+// for calls of many regions, few regions and one region cut by read ranges, and eight threads whose one-region
+// calls are combined into shared passes.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "../include/gatk_pairhmm.h"
@@ -194,6 +197,55 @@ int main(int argc, char** argv) {
     const double d4 = worst_difference(all, mid);
     CHECK(gatk_pairhmm_close(h4));
     if (!(d3 <= 2e-3) || !(d4 <= 2e-3)) { std::printf("default handle differs: %g %g\nFAILED\n", d3, d4); return 1; }
+
+    // one handle over three engines on GPU 0: the whole list (regions dealt out by cells), calls of a few regions
+    // (regions cut by read ranges), one region per call
+    {
+        gatk_pairhmm* hm = nullptr;
+        const int32_t devices[3] = {0, 0, 0};
+        CHECK(gatk_pairhmm_create_multi(devices, 3, &hm));
+        CHECK(gatk_pairhmm_set_option(hm, "multi_min_pairs", 64));
+        auto multi = outputs();
+        { auto p = pointers(multi); CHECK(gatk_pairhmm_compute_regions(hm, num_regions, batches.data(), p.data())); }
+        const double d5 = worst_difference(all, multi);
+        auto few = outputs();
+        {
+            auto p = pointers(few);
+            for (int at = 0; at < num_regions;) {
+                const int n = std::min(num_regions - at, g.range(1, 4));
+                CHECK(gatk_pairhmm_compute_regions(hm, n, batches.data() + at, p.data() + at));
+                at += n;
+            }
+        }
+        const double d6 = worst_difference(all, few);
+        CHECK(gatk_pairhmm_close(hm));
+        if (!(d5 <= 2e-3) || !(d6 <= 2e-3)) { std::printf("multi-device handle differs: %g %g\nFAILED\n", d5, d6); return 1; }
+    }
+
+    // eight caller threads, a handle each, one region per call, calls combined into shared passes
+    {
+        constexpr int kThreads = 8;
+        auto combined = outputs();
+        std::vector<int> failed(kThreads, 0);
+        std::vector<std::thread> threads;
+        for (int t = 0; t < kThreads; ++t)
+            threads.emplace_back([&, t]() {
+                gatk_pairhmm* hc = nullptr;
+                if (gatk_pairhmm_create(0, &hc) != 0 || gatk_pairhmm_set_option(hc, "combine_calls", 1) != 0) { failed[t] = 1; return; }
+                for (int k = t; k < num_regions; k += kThreads)
+                    if (gatk_pairhmm_compute_likelihoods(hc, &batches[k], combined[k].empty() ? nullptr : combined[k].data()) != 0) {
+                        std::printf("thread %d region %d: %s\n", t, k, gatk_pairhmm_last_error());
+                        failed[t] = 1;
+                        break;
+                    }
+                if (gatk_pairhmm_close(hc) != 0) failed[t] = 1;
+            });
+        for (auto& th : threads) th.join();
+        for (int t = 0; t < kThreads; ++t)
+            if (failed[t]) { std::printf("combined calls: thread %d failed\nFAILED\n", t); return 1; }
+        const double d7 = worst_difference(all, combined);
+        if (!(d7 <= 2e-3)) { std::printf("combined calls differ: %g\nFAILED\n", d7); return 1; }
+    }
 
     // the queueing interface and the single-pair call on the first region that has a read
     for (auto& r : regions) {
