@@ -510,8 +510,6 @@ void scan_alphabet(const uint8_t* p, int len, bool& has_n, bool& has_other) {
     }
 }
 
-constexpr int kDefaultIndelQual = 45;  // sam/GATKSAMRecord.java:61,298-322: reads without insertion / deletion qualities get a flat Q45
-constexpr int kDefaultGcp = 10;        // the constant gap-continuation penalty HaplotypeCaller passes (upstream; not in the reference tree)
 
 // A memcpy into the staging buffer.
 struct CopyJob {
@@ -860,8 +858,8 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     // ---- pass 2: lay the call out in the pinned staging buffer, one H2D copy ---------------------
     ArenaLayout L;
     const size_t rbytes = static_cast<size_t>(total_read_bytes);
-    // An optional per-base array that no region of the call supplies is not staged or copied at all: it
-    // goes behind everything that is uploaded and is filled with its default on the device.
+    // An optional per-base array that no region of the call supplies is not staged or copied at all: the
+    // kernels get a null pointer and take the default for every base.
     bool have_ins = false, have_del = false, have_gcp = false, have_mapq = false;
     for (int k = 0; k < num_regions; ++k) {
         const gatk_pairhmm_batch& b = regions[k];
@@ -885,8 +883,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     const size_t o_sdescs = L.add((stream_descs.size() + 1) * sizeof(StreamDesc));
     const size_t o_rinfo = L.add((total_reads + 1) * sizeof(ReadInfo));
     const size_t upload_bytes = L.size;
-    const size_t o_ri = have_ins ? o_ri_up : L.add(rbytes + 16), o_rd = have_del ? o_rd_up : L.add(rbytes + 16),
-                 o_rg = have_gcp ? o_rg_up : L.add(rbytes + 16);
+    const size_t o_ri = o_ri_up, o_rd = o_rd_up, o_rg = o_rg_up;
 
     HIP_TRY(hipSetDevice(h->device));
     if (int rc = record_stage_in_event(h)) return rc;
@@ -972,14 +969,11 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     // upload_bytes is a multiple of 256 and the staging buffer is at least as large
     if (upload_bytes > 0 && upload_bytes <= h->kernel_upload_bytes) HIP_TRY(launch_upload(S, R->d_arena.p, upload_bytes, s));
     else if (upload_bytes) HIP_TRY(hipMemcpyAsync(R->d_arena.p, S, upload_bytes, hipMemcpyHostToDevice, s));
-    uint8_t* const Dw = R->d_arena.as<uint8_t>();
-    if (!have_ins) HIP_TRY(hipMemsetAsync(Dw + o_ri, kDefaultIndelQual, rbytes + 16, s));
-    if (!have_del) HIP_TRY(hipMemsetAsync(Dw + o_rd, kDefaultIndelQual, rbytes + 16, s));
-    if (!have_gcp) HIP_TRY(hipMemsetAsync(Dw + o_rg, kDefaultGcp, rbytes + 16, s));
     const uint8_t* D = R->d_arena.as<uint8_t>();
     DeviceBatch& B = R->base;
     B = DeviceBatch{};
-    B.read_bases = D + o_rb; B.read_quals = D + o_rq; B.ins_gop = D + o_ri; B.del_gop = D + o_rd; B.gcp = D + o_rg;
+    B.read_bases = D + o_rb; B.read_quals = D + o_rq;
+    B.ins_gop = have_ins ? D + o_ri : nullptr; B.del_gop = have_del ? D + o_rd : nullptr; B.gcp = have_gcp ? D + o_rg : nullptr;
     B.read_off = reinterpret_cast<const int32_t*>(D + o_roff);
     B.read_out_base = reinterpret_cast<const int32_t*>(D + o_rout);
     B.hap_pool = D + o_hpool;
@@ -1349,14 +1343,23 @@ int gatk_pairhmm_initialize(gatk_pairhmm* h, int32_t read_max_length, int32_t ha
 static int compute_regions_multi(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions, double* const* likelihoods);
 
 // compute_regions on a single-device handle.  checked: the caller has run check_region on every region already.
+#ifdef PAIRHMM_CALL_CLOCKS
+#define CALL_CLOCK(label) std::fprintf(stderr, "  %8.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - call_t0).count(), label)
+#else
+#define CALL_CLOCK(label)
+#endif
 static int compute_regions_single(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
                                   double* const* likelihoods, bool checked) {
+#ifdef PAIRHMM_CALL_CLOCKS
+    const auto call_t0 = std::chrono::steady_clock::now();
+#endif
     if (!checked)
         for (int k = 0; k < num_regions; ++k) {
             int read_max = 0, hap_max = 0;
             if (int rc = check_region(regions[k], k, &read_max, &hap_max)) return rc;
             note_call_maxima(h, regions[k], read_max, hap_max);
         }
+    CALL_CLOCK("checked");
     const RegionCallCount in_flight(h->device);
     // A region with more pairs than a part holds is cut by read ranges (its pairs are independent,
     // PairHMM.java:217): the pieces share its haplotypes and write into consecutive rows of its array.
@@ -1453,12 +1456,15 @@ static int compute_regions_single(gatk_pairhmm* h, int32_t num_regions, const ga
     for (int p = 0; p < parts && rc == GATK_PAIRHMM_OK; ++p) {
         gatk_pairhmm_resident* R = slot[p % depth];
         R->region_label_base = cuts[p];
+        CALL_CLOCK("part begins");
         rc = plan_and_upload(h, R, cuts[p + 1] - cuts[p], regions + cuts[p], true);
+        CALL_CLOCK("  planned, upload enqueued");
         if (rc == GATK_PAIRHMM_OK && R->total_pairs > 0) rc = enqueue_compute(h, R);
+        CALL_CLOCK("  kernels enqueued");
         if (rc == GATK_PAIRHMM_OK) enqueued = p + 1;
-        if (rc == GATK_PAIRHMM_OK && p >= depth - 1) { rc = fetch(p - (depth - 1)); fetched = p - (depth - 1) + 1; }
+        if (rc == GATK_PAIRHMM_OK && p >= depth - 1) { rc = fetch(p - (depth - 1)); fetched = p - (depth - 1) + 1; CALL_CLOCK("  fetched an earlier part"); }
     }
-    while (rc == GATK_PAIRHMM_OK && fetched < enqueued) { rc = fetch(fetched); ++fetched; }
+    while (rc == GATK_PAIRHMM_OK && fetched < enqueued) { rc = fetch(fetched); ++fetched; CALL_CLOCK("fetched"); }
     if (rc != GATK_PAIRHMM_OK) {  // leave nothing in flight on buffers the next call will reuse
         const std::string msg = g_last_error;
         (void)hipStreamSynchronize(h->stream);

@@ -111,14 +111,16 @@ constexpr int kStreamBackPad = 128;  // entries behind it: draining lanes and th
 // the method that applies them is upstream of the reference tree).
 constexpr unsigned kBaseQualityScoreThreshold = 18;
 constexpr unsigned kMinUsableQScore = 6;
+constexpr int kDefaultIndelQual = 45;  // sam/GATKSAMRecord.java:61,298-322: reads without insertion / deletion qualities get a flat Q45
+constexpr int kDefaultGcp = 10;        // the constant gap-continuation penalty HaplotypeCaller passes (upstream; not in the reference tree)
 
 // Kernel arguments.  All pointers are device pointers.
 struct DeviceBatch {
     const uint8_t* read_bases;
     const uint8_t* read_quals;
-    const uint8_t* ins_gop;
-    const uint8_t* del_gop;
-    const uint8_t* gcp;
+    const uint8_t* ins_gop;        // null: every base kDefaultIndelQual
+    const uint8_t* del_gop;        // null: every base kDefaultIndelQual
+    const uint8_t* gcp;            // null: every base kDefaultGcp
     const uint8_t* read_mapq;      // [num_reads] cap on the read's base qualities, or null
     int32_t squash_base_quals;     // 1: base qualities under 18 count as 6
     double mismatch_divisor;       // 3: the tristate correction of Log10PairHMM.java:157; 1 with doNotUseTristateCorrection

@@ -212,6 +212,12 @@ struct LaneInfo {
     int seg_last;   // 1 if this lane holds the read's last row
 };
 
+// The optional per-base arrays: a call in which no read has one passes a null pointer and every base takes the
+// default (flat Q45 insertion / deletion qualities, sam/GATKSAMRecord.java:61,298-322; gap-continuation penalty 10).
+__device__ __forceinline__ unsigned ins_byte_at(const DeviceBatch& B, const int idx) { return B.ins_gop ? B.ins_gop[idx] : static_cast<unsigned>(kDefaultIndelQual); }
+__device__ __forceinline__ unsigned del_byte_at(const DeviceBatch& B, const int idx) { return B.del_gop ? B.del_gop[idx] : static_cast<unsigned>(kDefaultIndelQual); }
+__device__ __forceinline__ unsigned gcp_byte_at(const DeviceBatch& B, const int idx) { return B.gcp ? B.gcp[idx] : static_cast<unsigned>(kDefaultGcp); }
+
 // Entry i of a read's RowConst list (0: the pad row above row 1, 1..R: the read's rows, R + 1: the sum row)
 // from the quality bytes, with the checks the reference makes while expanding a read's qualities
 // (PairHMMModel.java:136-138: negative ins/del/GCP byte -> IllegalArgumentException, bit 0 of `bad`;
@@ -223,7 +229,7 @@ __device__ __forceinline__ RowConst make_row_const(const DeviceBatch& B, const i
     double t2 = 0.0, t4 = 1.0;  // a pad row hands its deletion mass down unweighted
     if (i >= 1 && i <= R) {
         const unsigned x = B.read_bases[ro + i - 1];
-        const unsigned ins_byte = B.ins_gop[ro + i - 1], del_byte = B.del_gop[ro + i - 1], gcp_byte = B.gcp[ro + i - 1];
+        const unsigned ins_byte = ins_byte_at(B, ro + i - 1), del_byte = del_byte_at(B, ro + i - 1), gcp_byte = gcp_byte_at(B, ro + i - 1);
         if ((ins_byte | del_byte | gcp_byte) & 0x80u) bad |= 1;
         const unsigned qual = effective_qual(B, ro + i - 1, read);  // what the PairHMM is handed: after the mapping-quality cap
         if (qual == 255) bad |= 2;
@@ -240,8 +246,8 @@ __device__ __forceinline__ RowConst make_row_const(const DeviceBatch& B, const i
         c.base = x;
     }
     if (i < R) {  // transitions of read row i + 1, taken from quals[i]
-        const unsigned ins = B.ins_gop[ro + i] & 127u, del = B.del_gop[ro + i] & 127u;
-        const double eg = B.err_prob[B.gcp[ro + i]];
+        const unsigned ins = ins_byte_at(B, ro + i) & 127u, del = del_byte_at(B, ro + i) & 127u;
+        const double eg = B.err_prob[gcp_byte_at(B, ro + i)];
         const double t0n = B.match_to_match[ins * 128u + del];
         const double t1n = 1.0 - eg;
         if (i >= 1) {
@@ -414,8 +420,8 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
                     xb = x;
                     p = 1.0 - e;                         // QualityUtils.qualToProb
                     q = (x == 'N') ? p : e / B.mismatch_divisor;        // a read 'N' matches every base
-                    t4 = B.err_prob[B.del_gop[ro + i - 1] & 127u];  // matchToDeletion
-                    t5 = B.err_prob[B.gcp[ro + i - 1]];             // deletionToDeletion
+                    t4 = B.err_prob[del_byte_at(B, ro + i - 1) & 127u];  // matchToDeletion
+                    t5 = B.err_prob[gcp_byte_at(B, ro + i - 1)];             // deletionToDeletion
                 } else {
                     pad = true;
                     t4 = 1.0;
@@ -423,8 +429,8 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
                     if (i < 0) t1n = 1.0;  // next row is a pad row too: anything finite
                 }
                 if (i >= 0 && i < R) {  // transitions of read row i+1, taken from quals[i]
-                    const unsigned ins = B.ins_gop[ro + i] & 127u, del = B.del_gop[ro + i] & 127u;
-                    const double eg = B.err_prob[B.gcp[ro + i]];
+                    const unsigned ins = ins_byte_at(B, ro + i) & 127u, del = del_byte_at(B, ro + i) & 127u;
+                    const double eg = B.err_prob[gcp_byte_at(B, ro + i)];
                     has_next = true;
                     t0n = B.match_to_match[ins * 128u + del];
                     t1n = 1.0 - eg;          // indelToMatch
@@ -911,8 +917,8 @@ __device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_
                 xb = x;
                 p = 1.0 - e;
                 q = (x == 'N') ? p : e / B.mismatch_divisor;
-                t4 = B.err_prob[B.del_gop[ro + i - 1] & 127u];
-                t5 = B.err_prob[B.gcp[ro + i - 1]];
+                t4 = B.err_prob[del_byte_at(B, ro + i - 1) & 127u];
+                t5 = B.err_prob[gcp_byte_at(B, ro + i - 1)];
             } else {
                 pad = true;
                 t4 = 1.0;
@@ -920,8 +926,8 @@ __device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_
                 if (i < 0) t1n = 1.0;
             }
             if (i >= 0 && i < R) {
-                const unsigned ins = B.ins_gop[ro + i] & 127u, del = B.del_gop[ro + i] & 127u;
-                const double eg = B.err_prob[B.gcp[ro + i]];
+                const unsigned ins = ins_byte_at(B, ro + i) & 127u, del = del_byte_at(B, ro + i) & 127u;
+                const double eg = B.err_prob[gcp_byte_at(B, ro + i)];
                 has_next = true;
                 t0n = B.match_to_match[ins * 128u + del];
                 t1n = 1.0 - eg;

@@ -109,6 +109,32 @@ def test_forced_fp64_matches_oracle_closely(hmm, oracle):
         hmm.set_option("force_fp64", 0)
 
 
+@pytest.mark.parametrize("length", [300, 640, 700, 760, 830, 900, 1000, 1022])
+def test_long_reads_at_many_rows_per_lane(hmm, oracle, length):
+    """Reads that need 5 to 16 rows per lane with all 64 lanes at work, close enough to their haplotypes for finite
+    likelihoods (a random long read underflows to -infinity, which hides a wrong sum): through the fp32 pass with
+    its fp64 pair pass behind it, through one haplotype per work item, and with everything forced through fp64."""
+    rng = np.random.default_rng(1000 + length)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    hap = acgt[rng.integers(0, 4, 1100)]
+    read = hap[30:30 + length].copy()
+    read[::37] = acgt[(np.searchsorted(acgt, read[::37]) + 1) % 4]  # a mismatch every 37 bases
+    b = pack([(read, rng.integers(10, 40, length), None, None, None)], [hap, hap[:1000]])
+    want = ref(oracle, b, 1)
+    assert np.isfinite(want).all()
+    try:
+        for mode in (1, 0, -1):
+            hmm.set_option("stream_mode", mode)
+            assert_parity(hmm.compute_batch(b), want)
+        hmm.set_option("force_fp64", 1)
+        for mode in (1, 0):
+            hmm.set_option("stream_mode", mode)
+            assert_parity(hmm.compute_batch(b), want, tol=1e-9)
+    finally:
+        hmm.set_option("force_fp64", 0)
+        hmm.set_option("stream_mode", 1)
+
+
 def test_underflow_to_minus_infinity(hmm, oracle):
     b = pack([("A" * 400, [93] * 400, [93] * 400, [93] * 400, [93] * 400), ("ACGT" * 20, [30] * 80, None, None, None)],
              ["C" * 400, "ACGT" * 30])
