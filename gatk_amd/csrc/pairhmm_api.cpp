@@ -1646,12 +1646,19 @@ struct Combiner {
     static constexpr int kLingerMicroseconds = 10;  // a leader that finds fewer than kLingerBelow requests waits this long for more,
     static constexpr size_t kLingerBelow = 8;       // while another engine keeps the device busy
     static constexpr size_t kMaxRequestsPerPass = 64;
+    static constexpr int kSpinMicroseconds = 250;   // how long a waiting caller spins for the end of a pass before it sleeps,
+    static constexpr int kMaxSpinners = 12;         // and how many callers do so at once
     std::mutex m;
     std::condition_variable cv;
     std::deque<Request*> pending;
     gatk_pairhmm* engine[kEngines] = {};
     bool busy[kEngines] = {};
+    int spinners = 0;  // callers spinning for the end of a pass (under the mutex)
     std::atomic<uint64_t> passes_ended{0};  // changed under the mutex; waiting callers spin on it before they sleep
+#ifdef PAIRHMM_CALL_CLOCKS
+    uint64_t dbg_passes = 0, dbg_requests = 0;
+    double dbg_run_us = 0, dbg_size_hist[9] = {};
+#endif
 };
 
 std::mutex g_combiners_mutex;
@@ -1673,6 +1680,14 @@ void release_shared_engines_if_last() {
     for (auto& kv : g_combiners) {
         Combiner* c = kv.second;
         std::lock_guard<std::mutex> inner(c->m);
+#ifdef PAIRHMM_CALL_CLOCKS
+        if (c->dbg_passes) {
+            std::fprintf(stderr, "combiner: %llu passes, %.2f requests per pass, %.1f us per pass in the leader; passes by size/2:", (unsigned long long)c->dbg_passes,
+                         double(c->dbg_requests) / c->dbg_passes, c->dbg_run_us / c->dbg_passes);
+            for (double v : c->dbg_size_hist) std::fprintf(stderr, " %.0f", v);
+            std::fprintf(stderr, "\n");
+        }
+#endif
         for (int e = 0; e < Combiner::kEngines; ++e)
             if (c->engine[e] && !c->busy[e]) {
                 gatk_pairhmm_close(c->engine[e]);
@@ -1708,13 +1723,18 @@ int compute_combined(int device, bool squash, const gatk_pairhmm_batch* batch, d
             // A pass takes about a hundred microseconds and a sleeping thread tens of microseconds to wake up:
             // wait for the end of a pass by spinning first, and sleep only when that takes long.
             const uint64_t seen = c->passes_ended.load(std::memory_order_acquire);
+            const bool spin = c->spinners < Combiner::kMaxSpinners;  // the rest sleep: spinning callers must not take every core
+            if (spin) ++c->spinners;
             lock.unlock();
-            const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(250);
-            for (int k = 0; c->passes_ended.load(std::memory_order_acquire) == seen; ++k) {
-                _mm_pause();
-                if ((k & 63) == 63 && std::chrono::steady_clock::now() >= spin_until) break;
+            if (spin) {
+                const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(Combiner::kSpinMicroseconds);
+                for (int k = 0; c->passes_ended.load(std::memory_order_acquire) == seen; ++k) {
+                    _mm_pause();
+                    if ((k & 63) == 63 && std::chrono::steady_clock::now() >= spin_until) break;
+                }
             }
             lock.lock();
+            if (spin) --c->spinners;
             if (c->passes_ended.load(std::memory_order_acquire) == seen) c->cv.wait(lock);  // the counter changes under this mutex
             continue;
         }
@@ -1749,8 +1769,16 @@ int compute_combined(int device, bool squash, const gatk_pairhmm_batch* batch, d
             }
             else create_error = g_last_error;
         }
+#ifdef PAIRHMM_CALL_CLOCKS
+        const auto dbg_t0 = std::chrono::steady_clock::now();
+#endif
         if (create_rc == GATK_PAIRHMM_OK) run_combined(c->engine[e], reqs);
         lock.lock();
+#ifdef PAIRHMM_CALL_CLOCKS
+        c->dbg_run_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count();
+        ++c->dbg_passes; c->dbg_requests += reqs.size();
+        c->dbg_size_hist[std::min<size_t>(reqs.size(), 16) / 2] += 1;
+#endif
         for (Combiner::Request* r : reqs) {
             if (create_rc != GATK_PAIRHMM_OK) { r->rc = create_rc; r->error = create_error; }
             r->done = true;

@@ -135,6 +135,25 @@ def test_long_reads_at_many_rows_per_lane(hmm, oracle, length):
         hmm.set_option("stream_mode", 1)
 
 
+@pytest.mark.parametrize("read_len,jitter", [(620, 40), (800, 150), (1000, 300)])
+def test_batches_of_long_reads(hmm, oracle, read_len, jitter):
+    """Several wave-groups of long reads (11 to 16 rows per lane, lengths mixed) against haplotype runs, read from
+    their haplotypes so that the likelihoods are finite: stream pass with its pair pass, one haplotype per work
+    item with its fp64 list pass, and everything in fp64."""
+    b = synth.make_batch(24, 6, read_len, 1100, seed=read_len, len_jitter=jitter, gop_model="random")
+    want = ref(oracle, b)
+    assert np.isfinite(want).all()
+    try:
+        for mode in (1, 0):
+            hmm.set_option("stream_mode", mode)
+            assert_parity(hmm.compute_batch(b), want)
+        hmm.set_option("force_fp64", 1)
+        assert_parity(hmm.compute_batch(b), want, tol=1e-9)
+    finally:
+        hmm.set_option("force_fp64", 0)
+        hmm.set_option("stream_mode", 1)
+
+
 def test_underflow_to_minus_infinity(hmm, oracle):
     b = pack([("A" * 400, [93] * 400, [93] * 400, [93] * 400, [93] * 400), ("ACGT" * 20, [30] * 80, None, None, None)],
              ["C" * 400, "ACGT" * 30])

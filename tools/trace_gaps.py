@@ -2,13 +2,14 @@
 idle time start a new call; per call: span from first to last event, summed busy time (union of the events), the
 largest idle gaps inside the call.  usage: trace_gaps.py DIR PREFIX [GAP_US]"""
 import csv
+import re
 import sys
 
 d, prefix = sys.argv[1], sys.argv[2]
 call_gap = float(sys.argv[3]) * 1e3 if len(sys.argv) > 3 else 400e3
 ev = []
 for r in csv.DictReader(open(f"{d}/{prefix}_kernel_trace.csv")):
-    ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("::")[-1].split("(")[0]))
+    ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.match(r"[\w:]+", r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")).group(0).split("::")[-1]))
 try:
     for r in csv.DictReader(open(f"{d}/{prefix}_memory_copy_trace.csv")):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r["Direction"]))

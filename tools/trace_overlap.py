@@ -3,6 +3,7 @@ and over the busy window the fraction of time with 0, 1, 2, 3+ forward kernels r
 usage: trace_overlap.py DIR PREFIX [NAME_SUBSTRING_OF_THE_FORWARD_KERNEL]"""
 import collections
 import csv
+import re
 import sys
 
 d, prefix = sys.argv[1], sys.argv[2]
@@ -11,7 +12,7 @@ rows = list(csv.DictReader(open(f"{d}/{prefix}_kernel_trace.csv")))
 by = collections.defaultdict(list)
 edges = []
 for r in rows:
-    n = r["Kernel_Name"].split("::")[-1].split("(")[0]
+    n = re.match(r"[\w:]+", r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")).group(0).split("::")[-1]
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     by[n].append(e - s)
     if key in n:
@@ -30,3 +31,19 @@ for t, step in edges:
     prev = t
 tot = sum(hist.values())
 print("forward kernels running at once, share of the window:", {k: round(v / tot, 3) for k, v in sorted(hist.items())}, f"window {tot / 1e6:.1f} ms")
+# a short window of the timeline, one line per event, with the queue it ran on
+if len(sys.argv) > 4:
+    ev = []
+    for r in rows:
+        n = re.match(r"[\w:]+", r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")).group(0).split("::")[-1]
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n, r.get("Queue_Id", "?")))
+    try:
+        for r in csv.DictReader(open(f"{d}/{prefix}_memory_copy_trace.csv")):
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r["Direction"].replace("MEMORY_COPY_", ""), "-"))
+    except FileNotFoundError:
+        pass
+    ev.sort()
+    mid = len(ev) * 3 // 4
+    base = ev[mid][0]
+    for s, e, n, q in ev[mid:mid + int(sys.argv[4])]:
+        print(f"{(s - base) / 1e3:9.1f} us  +{(e - s) / 1e3:6.1f}  q{q:>3s}  {n}")
