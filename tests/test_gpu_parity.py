@@ -361,6 +361,24 @@ def test_full_size_large_batch_properties(hmm, oracle):
     assert st["rerun_pairs"] / st["pairs"] < 0.01
 
 
+def test_full_size_long_read_indel_stress_properties(hmm, oracle):
+    """4096 x 32, 250 bp / 1000 bp with 4 % indels (the configuration with the fp64 reruns) at full size: a random
+    sample of reads against every haplotype vs the oracle, read order changes no value (the pair pass redoes single
+    pairs, whatever shared a wave with them), every value a finite log10 probability, and the rerun rate in the
+    range the workload is built for."""
+    b = synth.config_c5(num_reads=4096, num_haps=32)
+    got = hmm.compute_batch(b)
+    st = hmm.stats()
+    assert np.isfinite(got).all() and (got <= 0).all()
+    assert 0.02 < st["rerun_pairs"] / st["pairs"] < 0.10
+    rng = np.random.default_rng(123)
+    pick = np.sort(rng.choice(b.num_reads, size=40, replace=False))
+    assert_parity(got[pick], ref(oracle, subset_reads(b, pick)))
+    perm = rng.permutation(b.num_reads)
+    shuffled = hmm.compute_batch(subset_reads(b, perm))
+    np.testing.assert_array_equal(shuffled, got[perm])
+
+
 def subset_reads(b, idx):
     parts = [slice(int(b.read_offsets[i]), int(b.read_offsets[i + 1])) for i in idx]
     cat = lambda a: np.concatenate([a[p] for p in parts])
