@@ -159,6 +159,16 @@ struct PinnedBuf {
         if (e == hipSuccess) cap = want;
         return e;
     }
+    // the same, keeping the first `keep` bytes of what the buffer holds
+    hipError_t ensure_keep(size_t bytes, size_t keep) {
+        if (bytes <= cap) return hipSuccess;
+        void* old = p;
+        p = nullptr; cap = 0;
+        hipError_t e = ensure(bytes);
+        if (e == hipSuccess && old && keep) memcpy(p, old, keep);
+        if (old) { const hipError_t f = hipHostFree(old); if (e == hipSuccess) e = f; }
+        return e;
+    }
     void release() {
         if (p) (void)hipHostFree(p);
         p = nullptr; cap = 0;
@@ -518,28 +528,42 @@ struct CopyJob {
     size_t bytes;
 };
 
-// Large calls are bound by these copies (five bytes per read base): split them over a few threads.
-void run_copies(const std::vector<CopyJob>& jobs) {
-    size_t total = 0;
-    for (const CopyJob& j : jobs) total += j.bytes;
-    const int threads = total < (size_t{4} << 20) ? 1 : static_cast<int>(std::min<size_t>(4, total >> 21));
-    auto run = [&](size_t lo, size_t hi) {
-        for (size_t k = lo; k < hi; ++k) memcpy(jobs[k].dst, jobs[k].src, jobs[k].bytes);
-    };
-    if (threads <= 1) { run(0, jobs.size()); return; }
+// Large calls are bound by these copies (five bytes per read base): they go to a few threads, which start as soon
+// as the jobs are known and run beside the planner's walk over the regions; a small call copies on its own thread.
+struct CopyCrew {
+    std::vector<CopyJob> jobs;
     std::vector<std::thread> pool;
-    size_t begin = 0, acc = 0;
-    int started = 0;
-    for (size_t k = 0; k < jobs.size(); ++k) {
-        acc += jobs[k].bytes;
-        if (acc >= total / threads && started + 1 < threads) {
-            pool.emplace_back(run, begin, k + 1);
-            begin = k + 1; acc = 0; ++started;
+    bool started = false;
+    static void run(const std::vector<CopyJob>* jobs, size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; ++k) memcpy((*jobs)[k].dst, (*jobs)[k].src, (*jobs)[k].bytes);
+    }
+    // jobs is complete and stays untouched until finish()
+    void start() {
+        size_t total = 0;
+        for (const CopyJob& j : jobs) total += j.bytes;
+        const int threads = total < (size_t{2} << 20) ? 0 : static_cast<int>(std::min<size_t>(4, 1 + (total >> 21)));
+        started = true;
+        if (threads == 0) return;  // finish() copies
+        size_t begin = 0, acc = 0;
+        for (size_t k = 0; k < jobs.size(); ++k) {
+            acc += jobs[k].bytes;
+            if (acc >= total / threads || k + 1 == jobs.size()) {
+                pool.emplace_back(run, &jobs, begin, k + 1);
+                begin = k + 1; acc = 0;
+            }
         }
     }
-    run(begin, jobs.size());
-    for (auto& t : pool) t.join();
-}
+    void finish() {
+        if (!started) return;
+        if (pool.empty()) run(&jobs, 0, jobs.size());
+        for (auto& t : pool) t.join();
+        pool.clear();
+        started = false;
+    }
+    ~CopyCrew() {  // an early return between start() and finish(): the threads still hold the staging buffer
+        for (auto& t : pool) t.join();
+    }
+};
 
 // Per-region planning record (host only).
 struct RegionPlan {
@@ -566,8 +590,16 @@ int record_stage_in_event(gatk_pairhmm* h) {
 }
 
 // checked: the caller has run check_region on these regions already (under their own indices)
+#ifdef PAIRHMM_CALL_CLOCKS
+#define PLAN_CLOCK(i) plan_clock[i] = now_ms()
+#else
+#define PLAN_CLOCK(i)
+#endif
 int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, const gatk_pairhmm_batch* regions, bool checked = false) {
     const double t_begin = now_ms();
+#ifdef PAIRHMM_CALL_CLOCKS
+    double plan_clock[8] = {};
+#endif
     if (num_regions < 0 || (num_regions > 0 && !regions)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "regions cannot be null");
     if (!checked)
         for (int k = 0; k < num_regions; ++k) {
@@ -599,6 +631,55 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     if (call_pairs >= (int64_t{1} << 31) || total_read_bytes >= (int64_t{1} << 31) || hap_pool_bytes >= (int64_t{1} << 31))
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "more than 2^31 pairs or bytes in one call");
 
+    // ---- the per-base read arrays lead the staging buffer: where they go depends on sizes only, so their copies
+    // start here, on threads of their own when they are large, and run beside the walk over the regions ----------
+    ArenaLayout L;
+    const size_t rbytes = static_cast<size_t>(total_read_bytes);
+    // An optional per-base array that no region of the call supplies is not staged or copied at all: the
+    // kernels get a null pointer and take the default for every base.
+    bool have_ins = false, have_del = false, have_gcp = false, have_mapq = false;
+    for (int k = 0; k < num_regions; ++k) {
+        const gatk_pairhmm_batch& b = regions[k];
+        if (b.num_reads == 0 || b.num_haps == 0) continue;
+        have_ins |= b.ins_gop != nullptr; have_del |= b.del_gop != nullptr; have_gcp |= b.gcp != nullptr;
+        have_mapq |= b.read_mapq != nullptr;
+    }
+    const size_t o_rb = L.add(rbytes + 16), o_rq = L.add(rbytes + 16);
+    const size_t o_ri = have_ins ? L.add(rbytes + 16) : 0, o_rd = have_del ? L.add(rbytes + 16) : 0, o_rg = have_gcp ? L.add(rbytes + 16) : 0;
+    const size_t bulk_bytes = L.size;
+    HIP_TRY(hipSetDevice(h->device));
+    if (int rc = record_stage_in_event(h)) return rc;
+    if (h->stage_in_busy) {  // the previous upload's copy out of the staging buffer
+        HIP_TRY(hipEventSynchronize(h->stage_in_copied));
+        h->stage_in_busy = false;
+    }
+    // room for the rest as well, generously: the buffer is not to move while the copies run
+    HIP_TRY(h->stage_in.ensure(bulk_bytes + static_cast<size_t>(hap_pool_bytes) + static_cast<size_t>(total_reads) * 64 +
+                               static_cast<size_t>(total_haps) * 400 + static_cast<size_t>(num_regions) * 512 + (size_t{64} << 10)));
+    CopyCrew crew;
+    {
+        uint8_t* const S0 = static_cast<uint8_t*>(h->stage_in.p);
+        crew.jobs.reserve(static_cast<size_t>(num_regions) * 5);
+        size_t rcur = 0;
+        for (int k = 0; k < num_regions; ++k) {
+            const gatk_pairhmm_batch& b = regions[k];
+            if (b.num_reads == 0 || b.num_haps == 0) continue;
+            const int bo = b.read_offsets[0];
+            const size_t total = static_cast<size_t>(b.read_offsets[b.num_reads] - bo);
+            crew.jobs.push_back({S0 + o_rb + rcur, b.read_bases + bo, total});
+            crew.jobs.push_back({S0 + o_rq + rcur, b.read_quals + bo, total});
+            // defaults for a region without the array, when other regions of the call have it
+            if (b.ins_gop) crew.jobs.push_back({S0 + o_ri + rcur, b.ins_gop + bo, total});
+            else if (have_ins) memset(S0 + o_ri + rcur, kDefaultIndelQual, total);
+            if (b.del_gop) crew.jobs.push_back({S0 + o_rd + rcur, b.del_gop + bo, total});
+            else if (have_del) memset(S0 + o_rd + rcur, kDefaultIndelQual, total);
+            if (b.gcp) crew.jobs.push_back({S0 + o_rg + rcur, b.gcp + bo, total});
+            else if (have_gcp) memset(S0 + o_rg + rcur, kDefaultGcp, total);
+            rcur += total;
+        }
+        crew.start();
+    }
+
     // a call that does not fill the device for long: one rows-per-lane value for all of it
     int call_k = h->force_rows_per_lane;
     if (call_k == 0 && call_pairs > 0 && call_pairs < h->per_group_factor * static_cast<int64_t>(h->wave_slots)) {
@@ -624,6 +705,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         call_k = choose_call_rows_per_lane(shapes, longest);
     }
 
+    PLAN_CLOCK(0);
     std::vector<RegionPlan> plans;
     plans.reserve(num_regions);
     std::vector<GroupDesc> groups;
@@ -728,6 +810,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         hap_cursor += nh;
     }
 
+    PLAN_CLOCK(1);
     // ---- buckets: one launch per rows-per-lane value; longest work items first -----------------
     std::vector<int> by_cost(plans.size());
     {
@@ -855,20 +938,8 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     R->total_read_bytes = total_read_bytes;
     R->num_neg_inf = static_cast<int32_t>(neg_inf_idx.size());
 
-    // ---- pass 2: lay the call out in the pinned staging buffer, one H2D copy ---------------------
-    ArenaLayout L;
-    const size_t rbytes = static_cast<size_t>(total_read_bytes);
-    // An optional per-base array that no region of the call supplies is not staged or copied at all: the
-    // kernels get a null pointer and take the default for every base.
-    bool have_ins = false, have_del = false, have_gcp = false, have_mapq = false;
-    for (int k = 0; k < num_regions; ++k) {
-        const gatk_pairhmm_batch& b = regions[k];
-        if (b.num_reads == 0 || b.num_haps == 0) continue;
-        have_ins |= b.ins_gop != nullptr; have_del |= b.del_gop != nullptr; have_gcp |= b.gcp != nullptr;
-        have_mapq |= b.read_mapq != nullptr;
-    }
-    const size_t o_rb = L.add(rbytes + 16), o_rq = L.add(rbytes + 16);
-    const size_t o_ri_up = have_ins ? L.add(rbytes + 16) : 0, o_rd_up = have_del ? L.add(rbytes + 16) : 0, o_rg_up = have_gcp ? L.add(rbytes + 16) : 0;
+    PLAN_CLOCK(2);
+    // ---- pass 2: the rest of the call's image in the pinned staging buffer, one H2D copy -------------
     const size_t o_mapq = have_mapq ? L.add(static_cast<size_t>(total_reads) + 16) : 0;
     const size_t o_roff = L.add((total_reads + 1) * sizeof(int32_t));
     const size_t o_rout = L.add((total_reads + 1) * sizeof(int32_t));
@@ -883,15 +954,10 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     const size_t o_sdescs = L.add((stream_descs.size() + 1) * sizeof(StreamDesc));
     const size_t o_rinfo = L.add((total_reads + 1) * sizeof(ReadInfo));
     const size_t upload_bytes = L.size;
-    const size_t o_ri = o_ri_up, o_rd = o_rd_up, o_rg = o_rg_up;
-
-    HIP_TRY(hipSetDevice(h->device));
-    if (int rc = record_stage_in_event(h)) return rc;
-    if (h->stage_in_busy) {  // the previous upload's copy out of the staging buffer
-        HIP_TRY(hipEventSynchronize(h->stage_in_copied));
-        h->stage_in_busy = false;
+    if (upload_bytes > h->stage_in.cap) {  // the estimate fell short: let the copies finish, then move what they wrote
+        crew.finish();
+        HIP_TRY(h->stage_in.ensure_keep(upload_bytes, bulk_bytes));
     }
-    HIP_TRY(h->stage_in.ensure(upload_bytes));
     uint8_t* S = static_cast<uint8_t*>(h->stage_in.p);
     int32_t* roff = reinterpret_cast<int32_t*>(S + o_roff);
     int32_t* rout = reinterpret_cast<int32_t*>(S + o_rout);
@@ -902,23 +968,12 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     size_t rcur = 0, hcur = 0;
     int ri = 0, hi = 0;
     roff[0] = 0;
-    std::vector<CopyJob> copies;  // the bulk of the bytes: done at the end, on several threads when it pays
-    copies.reserve(static_cast<size_t>(num_regions) * 5);
     for (int k = 0; k < num_regions; ++k) {
         const gatk_pairhmm_batch& b = regions[k];
         const int nr = b.num_reads, nh = nr == 0 ? 0 : b.num_haps;
         if (nr == 0 || nh == 0) continue;
         const int bo = b.read_offsets[0];
         const size_t total = static_cast<size_t>(b.read_offsets[nr] - bo);
-        copies.push_back({S + o_rb + rcur, b.read_bases + bo, total});
-        copies.push_back({S + o_rq + rcur, b.read_quals + bo, total});
-        // defaults for a region without the array, when other regions of the call have it
-        if (b.ins_gop) copies.push_back({S + o_ri + rcur, b.ins_gop + bo, total});
-        else if (have_ins) memset(S + o_ri + rcur, kDefaultIndelQual, total);
-        if (b.del_gop) copies.push_back({S + o_rd + rcur, b.del_gop + bo, total});
-        else if (have_del) memset(S + o_rd + rcur, kDefaultIndelQual, total);
-        if (b.gcp) copies.push_back({S + o_rg + rcur, b.gcp + bo, total});
-        else if (have_gcp) memset(S + o_rg + rcur, kDefaultGcp, total);
         if (have_mapq) {
             if (b.read_mapq) memcpy(S + o_mapq + ri, b.read_mapq, static_cast<size_t>(nr));
             else memset(S + o_mapq + ri, 255, static_cast<size_t>(nr));
@@ -942,7 +997,9 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         }
     }
     memset(S + o_hpool + hcur, 0, 32);
-    run_copies(copies);
+    PLAN_CLOCK(3);
+    crew.finish();
+    PLAN_CLOCK(4);
     if (!groups.empty()) memcpy(S + o_groups, groups.data(), groups.size() * sizeof(GroupDesc));
     if (!segs.empty()) memcpy(S + o_segs, segs.data(), segs.size() * sizeof(SegDesc));
     if (!R->descs.empty()) memcpy(S + o_descs, R->descs.data(), R->descs.size() * sizeof(RegionDesc));
@@ -1008,6 +1065,12 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         if (int rc = record_stage_in_event(h)) return rc;
     R->plan_ms = t_planned - t_begin;
     R->upload_ms = now_ms() - t_planned;
+#ifdef PAIRHMM_CALL_CLOCKS
+    if (num_regions > 100)
+        std::fprintf(stderr, "    plan of %d regions: sizes %.0f us, region walk %.0f, buckets %.0f, layout and small copies %.0f, bulk copies %.0f, descriptors %.0f, enqueue %.0f\n",
+                     num_regions, (plan_clock[0] - t_begin) * 1e3, (plan_clock[1] - plan_clock[0]) * 1e3, (plan_clock[2] - plan_clock[1]) * 1e3,
+                     (plan_clock[3] - plan_clock[2]) * 1e3, (plan_clock[4] - plan_clock[3]) * 1e3, (t_planned - plan_clock[4]) * 1e3, R->upload_ms * 1e3);
+#endif
     return GATK_PAIRHMM_OK;
 }
 
