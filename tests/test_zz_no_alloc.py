@@ -80,6 +80,25 @@ def test_two_calls_in_a_row_match_the_allocating_entry_point():
         hmm.close()
 
 
+@pytest.mark.parametrize("read_len,jitter", [(640, 60), (1000, 300)])
+def test_long_reads(read_len, jitter):
+    """11 to 16 rows per lane (the variants whose fp64 pass does not fit the register file) through the
+    allocation-free entry point: same values as compute_likelihoods, and a smaller call behind it."""
+    torch = pytest.importorskip("torch")
+    hmm = HipLoglessPairHMM(0)
+    try:
+        long_reads = synth.make_batch(20, 5, read_len, 1100, seed=read_len + 1, len_jitter=jitter, gop_model="random")
+        small = synth.make_batch(5, 2, 90, 300, seed=3)
+        for b in (long_reads, small):
+            want = hmm.compute_batch(b)
+            rerun = hmm.stats()["rerun_pairs"]
+            got, status = run_noalloc(torch, hmm, b)
+            assert status == 0 and np.isfinite(got).all()
+            assert float(np.abs(got - want).max()) <= (1e-5 if rerun > 0 else 0.0)
+    finally:
+        hmm.close()
+
+
 def test_device_side_errors_come_back_in_the_status_word():
     torch = pytest.importorskip("torch")
     from gatk_amd.pairhmm import IllegalArgumentException
