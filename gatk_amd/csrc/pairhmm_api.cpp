@@ -776,7 +776,11 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         const int region_k = per_group ? 0 : choose_rows_per_lane(lens_desc, nh, mean_hap, call_pairs, call_k);
         size_t pos = 0;
         while (pos < order.size()) {
-            const int K = per_group ? choose_group_rows_per_lane(lens_desc[pos]) : region_k;
+            int K = per_group ? choose_group_rows_per_lane(lens_desc[pos]) : region_k;
+            // everything in double: from 10 rows per lane on the fp64 pass no longer fits the register file and
+            // spills, so reads that fit 8 rows per lane (up to 510 bases) take 8
+            if (h->force_fp64 && h->force_rows_per_lane == 0 && K > 8 && lens_desc[pos] + 2 <= 8 * kWave &&
+                (per_group || lens_desc.front() + 2 <= 8 * kWave)) K = 8;
             if (plans.empty() || plans.back().region != k || plans.back().K != K) {
                 rp.K = K;
                 rp.group_begin = static_cast<int>(groups.size());
