@@ -601,8 +601,8 @@ def test_random_shapes_and_options(hmm, oracle, seed):
     rng = np.random.default_rng(7000 + seed)
     regions = []
     for _ in range(int(rng.integers(1, 6))):
-        read_len = int(rng.choice([1, 7, 36, 76, 101, 151, 250, 400]))
-        hap_len = max(read_len, int(rng.choice([8, 60, 200, 420, 900])))
+        read_len = int(rng.choice([1, 7, 36, 76, 101, 151, 250, 400, 640, 900]))
+        hap_len = max(read_len, int(rng.choice([8, 60, 200, 420, 900, 1100])))
         b = synth.make_batch(int(rng.integers(1, 70)), int(rng.integers(1, 40)), read_len, hap_len, seed=int(rng.integers(1 << 30)),
                              len_jitter=int(rng.integers(0, read_len)), hap_len_jitter=int(rng.integers(0, max(1, hap_len // 3))),
                              qual_model=str(rng.choice(["illumina", "uniform"])), gop_model=str(rng.choice(["const", "random"])),
