@@ -338,9 +338,11 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     // sum therefore costs no instruction in the sweep.
     const T initD = static_cast<T>(::ldexp(1.0, Scale<T>::kExp2) / static_cast<double>(H));
     int ro = 0, R = 0;
+    int out_base = 0;  // fetched here, with the other per-read words: at the end of the sweep the load would stand alone
     if (ld.read_idx >= 0) {
         ro = B.read_off[ld.read_idx];
         R = B.read_off[ld.read_idx + 1] - ro;
+        out_base = B.read_out_base[ld.read_idx];
     }
     Rows<T, K> w;
     unsigned XB[K];
@@ -559,7 +561,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     if (ld.seg_last != 0 && ld.read_idx >= 0) {
         const T total = w.El[K - 1] + w.Ml[K - 1] + w.Sd[K - 1];  // the sum row, see above
         const double res = ::log10(static_cast<double>(total)) - Scale<T>::kExp2 * 0.30102999566398119521;
-        B.out[B.read_out_base[ld.read_idx] + hap_local] = res;
+        B.out[out_base + hap_local] = res;
         // too small for fp32 to be trusted, or NaN / infinity from the scaled form: redo in fp64
         if (kScaled) under = !(static_cast<float>(total) >= B.fp32_threshold && static_cast<float>(total) <= 3.0e38f);
     }

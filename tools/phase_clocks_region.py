@@ -1,12 +1,14 @@
 """Where a wave's cycles go in a region-sized call (one-haplotype fp32 pass): runs HaplotypeCaller-shaped regions one
-call each on the profiling build (make -C gatk_amd/csrc phase) and prints the per-phase share of wave cycles."""
+call each on the profiling build (make -C gatk_amd/csrc phase) and prints the per-phase share of wave cycles.  The
+build's counters are atomics on one address per phase: a global load that follows them in a wave (the termination's,
+before the per-read output base was fetched during set-up) waits for them to return, which inflates that phase."""
 import ctypes
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-lib = os.path.join(ROOT, "exp_build", "libphase.so")
+lib = os.environ.get("PHASE_LIB", os.path.join(ROOT, "exp_build", "libphase.so"))
 os.environ["GATK_PAIRHMM_LIB"] = lib
 from gatk_amd import synth  # noqa: E402
 from gatk_amd.pairhmm import HipLoglessPairHMM  # noqa: E402
