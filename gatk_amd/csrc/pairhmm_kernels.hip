@@ -484,7 +484,42 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
             emit(hp[step], prior);
             if (static_cast<unsigned>(step - ld.seg_lane) < static_cast<unsigned>(H)) column<T, K>(w, prior, Sin, Iin);
         };
-        for (; s < steady_begin; ++s) masked_step(s);
+        // Fill and drain in blocks of four steps with the same read-ahead as the steady blocks, up to 6 rows per lane
+        // (the values region-sized calls take: their waves are alone on a SIMD and would wait out two dependent LDS
+        // reads per step; with more rows the second set of emission terms costs registers that larger calls, whose
+        // other waves cover the latency, need for occupancy).  Every entry the read-ahead can touch holds a valid
+        // table offset: the pads in front of column 0 and behind column H - 1 are zeroed.
+        auto masked_run = [&](const int end) {
+            if constexpr (K <= 6) {
+                if (s + 4 <= end) {
+                    T mc[4][K];
+                    unsigned mn[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) emit(hp[s + u], mc[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) mn[u] = hp[s + 4 + u];
+                    for (; s + 4 <= end; s += 4) {
+                        T mx[4][K];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) emit(mn[u], mx[u]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) mn[u] = hp[s + 8 + u];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const T Sin = shr1(w.Sout);
+                            const T Iin = shr1(w.Iout);
+                            if (static_cast<unsigned>(s + u - ld.seg_lane) < static_cast<unsigned>(H)) column<T, K>(w, mc[u], Sin, Iin);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int r = 0; r < K; ++r) mc[u][r] = mx[u][r];
+                    }
+                }
+            }
+            for (; s < end; ++s) masked_step(s);
+        };
+        masked_run(steady_begin);
         PHASE_END(2);
         if (s + 4 <= H) {
             // two-deep software pipeline: emission terms of the next four columns and base codes of
@@ -514,7 +549,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
             }
         }
         PHASE_END(3);
-        for (; s < H + fill; ++s) masked_step(s);
+        masked_run(H + fill);
         PHASE_END(4);
     } else {
         const unsigned char* hp = hap_img + (kHapFrontPad - ld.seg_lane);
