@@ -331,6 +331,15 @@ def test_long_haplotype_and_length_cap(hmm, oracle):
     want = ref(oracle, b, 1)
     assert_parity(hmm.compute_batch(b), want)                                              # haplotype runs
     assert_parity(with_options(hmm, {"stream_mode": 0}, lambda: hmm.compute_batch(b)), want)  # one haplotype per item
+    # a long read against the same haplotypes: 16 rows per lane next to the largest LDS images
+    long_read = hap[7000:7900].copy()
+    long_read[::41] = acgt[(np.searchsorted(acgt, long_read[::41]) + 1) % 4]
+    b2 = pack([(long_read, rng.integers(10, 40, 900), None, None, None), (read, [30] * 100, None, None, None)], [hap, hap[:15000], hap[4000:9000]])
+    want2 = ref(oracle, b2, 1)
+    assert np.isfinite(want2).all()
+    assert_parity(hmm.compute_batch(b2), want2)
+    assert_parity(with_options(hmm, {"stream_mode": 0}, lambda: hmm.compute_batch(b2)), want2)
+    assert_parity(with_options(hmm, {"force_fp64": 1}, lambda: hmm.compute_batch(b2)), want2, tol=1e-9)
     with pytest.raises(pairhmm.IllegalArgumentException):
         hmm.compute_batch(pack([(read, [30] * 100, None, None, None)], [acgt[rng.integers(0, 4, 16001)]]))
 
@@ -443,7 +452,7 @@ def test_extreme_gap_quality_steps(hmm, oracle):
 # ---- haplotype runs (the fp32 stream pass) ------------------------------------------------------
 
 def with_options(hmm, opts, fn):
-    defaults = {"stream_mode": 1, "max_stream_haps": 16, "force_rows_per_lane": 0, "emit_mode": -1}  # the session handle's
+    defaults = {"stream_mode": 1, "max_stream_haps": 16, "force_rows_per_lane": 0, "emit_mode": -1, "force_fp64": 0}  # the session handle's
     for k, v in opts.items():
         hmm.set_option(k, v)
     try:
