@@ -448,25 +448,27 @@ int check_region(const gatk_pairhmm_batch& b, int k, int* read_max_out = nullptr
     if (b.num_reads == 0) return GATK_PAIRHMM_OK;  // PairHMM.java:193
     if (!b.read_offsets || !b.read_bases || !b.read_quals)  // insertion / deletion / GCP arrays may be null: defaults
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("readBases cannot be null") + where());
-    int read_max = 0, hap_max = 0;
+    // branch-free passes over the offset tables (they vectorise): a large call walks some hundred thousand entries here
+    int read_max = 0, hap_max = 0, read_min = 0, hap_min = std::numeric_limits<int>::max();
     for (int r = 0; r < b.num_reads; ++r) {
         const int len = b.read_offsets[r + 1] - b.read_offsets[r];
-        if (len < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("read offsets must not decrease") + where());
+        read_min = std::min(read_min, len);
         read_max = std::max(read_max, len);
     }
+    if (read_min < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("read offsets must not decrease") + where());
     if (b.num_haps > 0 && (!b.hap_offsets || !b.hap_bases))
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("haplotypeBases cannot be null") + where());
     for (int a = 0; a < b.num_haps; ++a) {
         const int len = b.hap_offsets[a + 1] - b.hap_offsets[a];
-        if (len < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("haplotype offsets must not decrease") + where());
+        hap_min = std::min(hap_min, len);
         hap_max = std::max(hap_max, len);
     }
+    if (b.num_haps > 0 && hap_min < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("haplotype offsets must not decrease") + where());
     // PairHMM.initialize, reached through PairHMM.java:200-201
     if (read_max <= 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "READ_MAX_LENGTH must be > 0 but got " + std::to_string(read_max) + where());
     if (hap_max <= 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "HAPLOTYPE_MAX_LENGTH must be > 0 but got " + std::to_string(hap_max) + where());
-    for (int a = 0; a < b.num_haps; ++a)
-        if (b.hap_offsets[a + 1] - b.hap_offsets[a] == 0)
-            return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("zero-length haplotype: the reference result is undefined") + where());
+    if (b.num_haps > 0 && hap_min == 0)
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("zero-length haplotype: the reference result is undefined") + where());
     if (read_max > kWave * kMaxRowsPerLane - 2)
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "readBases is too long, got " + std::to_string(read_max) + " but max is " +
                                                        std::to_string(kWave * kMaxRowsPerLane - 2) + where());
