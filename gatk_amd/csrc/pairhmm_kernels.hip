@@ -172,6 +172,28 @@ template <typename T, int K>
 __device__ __forceinline__ void column(Rows<T, K>& w, const T (&prior)[K], const T Sin, const T Iin) {
     T Iup = Iin;    // I (plain) or F (scaled) of the current row in this column
     T Snext = Sin;  // Sn of the row above in this column: next column's diagonal term
+    if constexpr (!IsScaled<T>::value) {
+        // The plain form runs under a lane mask in most of its callers (a lane outside its haplotype skips the
+        // column), where every new value that cannot take the register of the old one costs a copy at the end of
+        // the masked block.  In this order every state register is dead when its new value is made: E first (the
+        // last use of the old M), then M (the last use of the old diagonal term), then the hand-off chain, whose
+        // results are the next column's diagonal terms.  Same operations, same results.
+#pragma unroll
+        for (int r = 0; r < K; ++r) w.El[r] = fma_(w.El[r], w.T5[r], w.Ml[r]);
+#pragma unroll
+        for (int r = 0; r < K; ++r) w.Ml[r] = prior[r] * w.Sd[r];
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const T In = fma_(w.Ml[r], w.C[r], Iup * w.D[r]);
+            const T Sn = fma_(w.El[r], w.E[r], fma_(Iup, w.B[r], w.Ml[r] * w.A[r]));
+            w.Sd[r] = Snext;
+            Snext = Sn;
+            Iup = In;
+        }
+        w.Sout = Snext;
+        w.Iout = Iup;
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < K; ++r) {
         const T M = prior[r] * w.Sd[r];
