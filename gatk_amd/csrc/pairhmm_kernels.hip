@@ -216,6 +216,33 @@ __device__ __forceinline__ void column(Rows<T, K>& w, const T (&prior)[K], const
     w.Iout = Iup;
 }
 
+// The plain-form column for a loop whose steps alternate PARITY 0, 1, 0, 1 ...: the deletion term E = E' * t5 + M'
+// is an FMA whose addend is the old M, and the two-address v_fmac_f64 the compiler emits for it leaves the result in
+// the addend's register, so a column that must end with E in E's register pays two copies per row under a lane mask.
+// Here the two registers trade places every step instead: PARITY 0 finds (M', E') in (Ml, El) and leaves (E, M) there,
+// PARITY 1 finds (E', M') and leaves (M, E).  A lane whose first column falls on an odd step starts with the two
+// swapped; the final sum adds both, so it does not care.
+template <int K, int PARITY>
+__device__ __forceinline__ void column_swapping(Rows<double, K>& w, const double (&prior)[K], const double Sin, const double Iin) {
+    double (&Mslot)[K] = PARITY == 0 ? w.El : w.Ml;  // where this column's M goes
+    double (&Eslot)[K] = PARITY == 0 ? w.Ml : w.El;  // where its E goes: the register that held the old M
+#pragma unroll
+    for (int r = 0; r < K; ++r) Eslot[r] = fma_(Mslot[r], w.T5[r], Eslot[r]);  // old E sits in Mslot, old M in Eslot
+#pragma unroll
+    for (int r = 0; r < K; ++r) Mslot[r] = prior[r] * w.Sd[r];
+    double Iup = Iin, Snext = Sin;
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        const double In = fma_(Mslot[r], w.C[r], Iup * w.D[r]);
+        const double Sn = fma_(Eslot[r], w.E[r], fma_(Iup, w.B[r], Mslot[r] * w.A[r]));
+        w.Sd[r] = Snext;
+        Snext = Sn;
+        Iup = In;
+    }
+    w.Sout = Snext;
+    w.Iout = Iup;
+}
+
 // LDS image of one wave.
 //   compare modes: [64 pad][haplotype bytes][pad]                       (byte per base)
 //   table modes  : [K/2][codes][64][2] emission table | [64 pad][code*512 as u16 per base][pad]
@@ -1013,6 +1040,10 @@ __device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_
     w.Sout = w.El[K - 1] * w.E[K - 1];
     w.Iout = 0.0;
     w.Sd[0] = shr1(w.Sout);
+    if (t & 1) {  // this lane's first column is an odd step: column_swapping<K, 1> expects M and E in each other's place
+#pragma unroll
+        for (int r = 0; r < K; ++r) { const T e = w.El[r]; w.El[r] = w.Ml[r]; w.Ml[r] = e; }
+    }
     __builtin_amdgcn_wave_barrier();
 
     // the longest haplotype of the wave sets the number of steps
@@ -1037,17 +1068,20 @@ __device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_
     emit(codes.x & 0xffffu, pn);
     for (int s0 = 0; s0 < steps; s0 += 4) {
         const uint2 after = load_codes(hp + min(s0 + 8, last_block));
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        auto step = [&](auto parity_tag, const int u, const unsigned y_next) {
+            constexpr int kParity = decltype(parity_tag)::value;
             const T Sin = shr1(w.Sout);
             const T Iin = shr1(w.Iout);
             T pc[K];
 #pragma unroll
             for (int r = 0; r < K; ++r) pc[r] = pn[r];
-            const unsigned y_next = u == 0 ? (codes.x >> 16) : u == 1 ? (codes.y & 0xffffu) : u == 2 ? (codes.y >> 16) : (next_codes.x & 0xffffu);
             emit(y_next, pn);
-            if (static_cast<unsigned>(s0 + u - t) < static_cast<unsigned>(H)) column<T, K>(w, pc, Sin, Iin);
-        }
+            if (static_cast<unsigned>(s0 + u - t) < static_cast<unsigned>(H)) column_swapping<K, kParity>(w, pc, Sin, Iin);
+        };
+        step(std::integral_constant<int, 0>{}, 0, codes.x >> 16);
+        step(std::integral_constant<int, 1>{}, 1, codes.y & 0xffffu);
+        step(std::integral_constant<int, 0>{}, 2, codes.y >> 16);
+        step(std::integral_constant<int, 1>{}, 3, next_codes.x & 0xffffu);
         codes = next_codes;
         next_codes = after;
     }
