@@ -216,25 +216,34 @@ __device__ __forceinline__ void column(Rows<T, K>& w, const T (&prior)[K], const
     w.Iout = Iup;
 }
 
-// The plain-form column for a loop whose steps alternate PARITY 0, 1, 0, 1 ...: the deletion term E = E' * t5 + M'
-// is an FMA whose addend is the old M, and the two-address v_fmac_f64 the compiler emits for it leaves the result in
-// the addend's register, so a column that must end with E in E's register pays two copies per row under a lane mask.
-// Here the two registers trade places every step instead: PARITY 0 finds (M', E') in (Ml, El) and leaves (E, M) there,
-// PARITY 1 finds (E', M') and leaves (M, E).  A lane whose first column falls on an odd step starts with the two
-// swapped; the final sum adds both, so it does not care.
-template <int K, int PARITY>
-__device__ __forceinline__ void column_swapping(Rows<double, K>& w, const double (&prior)[K], const double Sin, const double Iin) {
-    double (&Mslot)[K] = PARITY == 0 ? w.El : w.Ml;  // where this column's M goes
-    double (&Eslot)[K] = PARITY == 0 ? w.Ml : w.El;  // where its E goes: the register that held the old M
+// The column for loops whose steps alternate PARITY 0, 1, 0, 1 ... and run under a lane mask (a lane outside its
+// haplotype skips the column).  Under a mask every new state value that cannot take the register of the old one costs a
+// copy at the end of the masked block, and the deletion term E = E' * t5 + M' is an FMA whose addend is the old M: the
+// two-address v_fmac the compiler emits for it leaves the result in the addend's register.  So the operations come in
+// an order in which every state register is dead when its new value is made (E first: the last use of the old M; then
+// M: the last use of the old diagonal term; then the hand-off chain, whose results are the next column's diagonal
+// terms), and M and E trade registers every step: PARITY 0 finds (M', E') in (Ml, El) and leaves (E, M) there, PARITY 1
+// finds (E', M') and leaves (M, E).  A lane whose first column falls on an odd step starts with the two swapped; the
+// final sum adds both, so it does not care.  Same operations as column(), same results.
+template <typename T, int K, int PARITY>
+__device__ __forceinline__ void column_swapping(Rows<T, K>& w, const T (&prior)[K], const T Sin, const T Iin) {
+    T (&Mslot)[K] = PARITY == 0 ? w.El : w.Ml;  // where this column's M goes: the register that held the old E
+    T (&Eslot)[K] = PARITY == 0 ? w.Ml : w.El;  // where its E goes: the register that held the old M
 #pragma unroll
     for (int r = 0; r < K; ++r) Eslot[r] = fma_(Mslot[r], w.T5[r], Eslot[r]);  // old E sits in Mslot, old M in Eslot
 #pragma unroll
     for (int r = 0; r < K; ++r) Mslot[r] = prior[r] * w.Sd[r];
-    double Iup = Iin, Snext = Sin;
+    T Iup = Iin, Snext = Sin;
 #pragma unroll
     for (int r = 0; r < K; ++r) {
-        const double In = fma_(Mslot[r], w.C[r], Iup * w.D[r]);
-        const double Sn = fma_(Eslot[r], w.E[r], fma_(Iup, w.B[r], Mslot[r] * w.A[r]));
+        T In, Sn;
+        if (IsScaled<T>::value) {
+            In = fma_(Iup, w.A[r], Mslot[r]);
+            Sn = fma_(Eslot[r], w.C[r], fma_(Iup, w.B[r], Mslot[r]));
+        } else {
+            In = fma_(Mslot[r], w.C[r], Iup * w.D[r]);
+            Sn = fma_(Eslot[r], w.E[r], fma_(Iup, w.B[r], Mslot[r] * w.A[r]));
+        }
         w.Sd[r] = Snext;
         Snext = Sn;
         Iup = In;
@@ -526,12 +535,22 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
         const uint16_t* hp = reinterpret_cast<const uint16_t*>(hap_img) + (kHapFrontPad - ld.seg_lane);
         const unsigned char* tbl_lane = slice + lane * 4 * kLutRowsPerRead;
         auto emit = [&](const unsigned code_off, T (&prior)[K]) { lut_emit<T, K, kCodes>(tbl_lane, code_off, prior); };
+        // Every column of this sweep is a column_swapping of its step's parity (in the unrolled blocks, which start on
+        // even steps, the parity is a constant): a lane whose first column is an odd step starts with M and E swapped.
+        if (ld.seg_lane & 1) {
+#pragma unroll
+            for (int r = 0; r < K; ++r) { const T e = w.El[r]; w.El[r] = w.Ml[r]; w.Ml[r] = e; }
+        }
+        auto col = [&](const int parity, const T (&prior)[K], const T Sin, const T Iin) {
+            if (parity & 1) column_swapping<T, K, 1>(w, prior, Sin, Iin);
+            else column_swapping<T, K, 0>(w, prior, Sin, Iin);
+        };
         auto masked_step = [&](const int step) {
             const T Sin = shr1(w.Sout);
             const T Iin = shr1(w.Iout);
             T prior[K];
             emit(hp[step], prior);
-            if (static_cast<unsigned>(step - ld.seg_lane) < static_cast<unsigned>(H)) column<T, K>(w, prior, Sin, Iin);
+            if (static_cast<unsigned>(step - ld.seg_lane) < static_cast<unsigned>(H)) col(step, prior, Sin, Iin);
         };
         // Fill and drain in blocks of four steps with the same read-ahead as the steady blocks, up to 6 rows per lane
         // (the values region-sized calls take: their waves are alone on a SIMD and would wait out two dependent LDS
@@ -540,6 +559,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
         // table offset: the pads in front of column 0 and behind column H - 1 are zeroed.
         auto masked_run = [&](const int end) {
             if constexpr (K <= 6) {
+                if ((s & 1) && s < end) { masked_step(s); ++s; }
                 if (s + 4 <= end) {
                     T mc[4][K];
                     unsigned mn[4];
@@ -557,7 +577,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
                         for (int u = 0; u < 4; ++u) {
                             const T Sin = shr1(w.Sout);
                             const T Iin = shr1(w.Iout);
-                            if (static_cast<unsigned>(s + u - ld.seg_lane) < static_cast<unsigned>(H)) column<T, K>(w, mc[u], Sin, Iin);
+                            if (static_cast<unsigned>(s + u - ld.seg_lane) < static_cast<unsigned>(H)) col(u, mc[u], Sin, Iin);
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
@@ -569,6 +589,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
             for (; s < end; ++s) masked_step(s);
         };
         masked_run(steady_begin);
+        if (s & 1) { masked_step(s); ++s; }  // the steady blocks start on an even step
         PHASE_END(2);
         if (s + 4 <= H) {
             // two-deep software pipeline: emission terms of the next four columns and base codes of
@@ -589,7 +610,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
                 for (int u = 0; u < 4; ++u) {
                     const T Sin = shr1(w.Sout);
                     const T Iin = shr1(w.Iout);
-                    column<T, K>(w, pc[u], Sin, Iin);
+                    col(u, pc[u], Sin, Iin);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -1076,7 +1097,7 @@ __device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_
 #pragma unroll
             for (int r = 0; r < K; ++r) pc[r] = pn[r];
             emit(y_next, pn);
-            if (static_cast<unsigned>(s0 + u - t) < static_cast<unsigned>(H)) column_swapping<K, kParity>(w, pc, Sin, Iin);
+            if (static_cast<unsigned>(s0 + u - t) < static_cast<unsigned>(H)) column_swapping<T, K, kParity>(w, pc, Sin, Iin);
         };
         step(std::integral_constant<int, 0>{}, 0, codes.x >> 16);
         step(std::integral_constant<int, 1>{}, 1, codes.y & 0xffffu);
