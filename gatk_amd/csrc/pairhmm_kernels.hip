@@ -530,21 +530,21 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
     //   [max(H, fill), H+fill) pipeline drain: lanes with s - t >= H are done  -> masked
     const int steady_begin = fill < H ? fill : H;
     int s = 0;
+    // Every column of the sweep is a column_swapping of its step's parity (in the unrolled blocks, which start on even
+    // steps, the parity is a constant): a lane whose first column is an odd step starts with M and E swapped.
+    if (ld.seg_lane & 1) {
+#pragma unroll
+        for (int r = 0; r < K; ++r) { const T e = w.El[r]; w.El[r] = w.Ml[r]; w.Ml[r] = e; }
+    }
+    auto col = [&](const int parity, const T (&prior)[K], const T Sin, const T Iin) {
+        if (parity & 1) column_swapping<T, K, 1>(w, prior, Sin, Iin);
+        else column_swapping<T, K, 0>(w, prior, Sin, Iin);
+    };
     PHASE_END(1);
     if (kLut) {
         const uint16_t* hp = reinterpret_cast<const uint16_t*>(hap_img) + (kHapFrontPad - ld.seg_lane);
         const unsigned char* tbl_lane = slice + lane * 4 * kLutRowsPerRead;
         auto emit = [&](const unsigned code_off, T (&prior)[K]) { lut_emit<T, K, kCodes>(tbl_lane, code_off, prior); };
-        // Every column of this sweep is a column_swapping of its step's parity (in the unrolled blocks, which start on
-        // even steps, the parity is a constant): a lane whose first column is an odd step starts with M and E swapped.
-        if (ld.seg_lane & 1) {
-#pragma unroll
-            for (int r = 0; r < K; ++r) { const T e = w.El[r]; w.El[r] = w.Ml[r]; w.Ml[r] = e; }
-        }
-        auto col = [&](const int parity, const T (&prior)[K], const T Sin, const T Iin) {
-            if (parity & 1) column_swapping<T, K, 1>(w, prior, Sin, Iin);
-            else column_swapping<T, K, 0>(w, prior, Sin, Iin);
-        };
         auto masked_step = [&](const int step) {
             const T Sin = shr1(w.Sout);
             const T Iin = shr1(w.Iout);
@@ -638,10 +638,11 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
             if (static_cast<unsigned>(step - ld.seg_lane) < static_cast<unsigned>(H)) {
                 T prior[K];
                 emit(yb, prior);
-                column<T, K>(w, prior, Sin, Iin);
+                col(step, prior, Sin, Iin);
             }
         };
         for (; s < steady_begin; ++s) masked_step(s);
+        if (s & 1) { masked_step(s); ++s; }  // the steady blocks start on an even step
         if (s + 4 <= H) {
             unsigned n0 = hp[s], n1 = hp[s + 1], n2 = hp[s + 2], n3 = hp[s + 3];
             for (; s + 4 <= H; s += 4) {
@@ -654,7 +655,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
                     const T Iin = shr1(w.Iout);
                     T prior[K];
                     emit(u == 0 ? y0 : u == 1 ? y1 : u == 2 ? y2 : y3, prior);
-                    column<T, K>(w, prior, Sin, Iin);
+                    col(u, prior, Sin, Iin);
                 }
             }
         }
