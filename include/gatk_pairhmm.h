@@ -173,7 +173,8 @@ int gatk_pairhmm_device_count(int32_t* count);
 
 /* Engine tunables (all optional).  Planning options take effect at the next upload or host-pointer call.
  *   "fp32_threshold"      default 1e-28: a pair whose scaled fp32 sum falls below it is recomputed in fp64.
- *   "force_fp64"          1 = score everything in fp64.
+ *   "force_fp64"          1 = score everything in fp64 (batches planned while it is set take at most 8 rows per
+ *                         lane where the reads fit, the most the fp64 pass holds in registers).
  *   "force_rows_per_lane" 0 = automatic.
  *   "emit_mode"           -1 = automatic, 0 = always compare bases instead of using the per-wave emission table.
  *   "timing"              1 = fill the *_kernel_ms stats.
