@@ -1166,6 +1166,7 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
                 HIP_TRY(launch_pairs(L, bk.pair_rows_per_lane, static_cast<int>(std::min<int64_t>(waves, 8192)), s));
                 continue;
             }
+            if (bk.rows_per_lane <= kInlineRerunRows) continue;  // the fp32 pass has redone those items itself
             const int blocks = std::min((bk.num_tasks + kWavesPerBlock - 1) / kWavesPerBlock, 1024);
             HIP_TRY(launch_forward(bucket_args(bi, bk.emit_mode_fp64), bk.rows_per_lane, bk.emit_mode_fp64, true, true, blocks, s));
         }
@@ -2447,7 +2448,8 @@ extern "C" int gatk_pairhmm_compute_likelihoods_noalloc(gatk_pairhmm* h, void* s
     B.lds_per_wave = lds;
     const int blocks = static_cast<int>((tasks + kWavesPerBlock - 1) / kWavesPerBlock);
     HIP_TRY(launch_forward(B, K, kEmitCompareN, false, false, blocks, s));
-    HIP_TRY(launch_forward(B, K, kEmitCompareN, true, true, std::min(blocks, 1024), s));
+    if (K > kInlineRerunRows)  // with fewer rows per lane the fp32 pass redoes its underflowing items itself
+        HIP_TRY(launch_forward(B, K, kEmitCompareN, true, true, std::min(blocks, 1024), s));
     return GATK_PAIRHMM_OK;
 }
 

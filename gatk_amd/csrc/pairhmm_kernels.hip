@@ -322,7 +322,7 @@ __device__ __forceinline__ RowConst make_row_const(const DeviceBatch& B, const i
 }
 
 template <typename T, int K, int MODE>
-__device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_idx, unsigned char* slice,
+__device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_idx, unsigned char* slice,
                                          const int lane, const bool queue_underflow) {
     constexpr bool kScaled = IsScaled<T>::value;
     constexpr bool kLut = is_lut(MODE);
@@ -671,8 +671,10 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
         // too small for fp32 to be trusted, or NaN / infinity from the scaled form: redo in fp64
         if (kScaled) under = !(static_cast<float>(total) >= B.fp32_threshold && static_cast<float>(total) <= 3.0e38f);
     }
+    bool again = false;  // wave-uniform: some pair of this work item has to be redone in fp64
     if (queue_underflow) {
-        if (__any(under ? 1 : 0)) {
+        again = __any(under ? 1 : 0) != 0;
+        if (again) {
             if (lane == 0) {
                 const int pos = atomicAdd(B.rerun_count, 1);
                 B.rerun_list[pos] = task_idx;
@@ -683,6 +685,7 @@ __device__ __forceinline__ void run_task(const DeviceBatch& B, const int task_id
 #ifdef PAIRHMM_PHASE_CLOCKS
     if (lane == 0) atomicAdd(&g_phase_clocks[6], 1ull);
 #endif
+    return again;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1208,7 +1211,17 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_direct(const Device
     const int task = blockIdx.x * kWavesPerBlock + wave;
     if (task >= B.num_tasks) return;
     if (B.abort_word != nullptr && (*B.abort_word & kAbortBit) != 0) return;
-    run_task<T, K, MODE>(B, task, lds + wave * B.lds_per_wave, lane, std::is_same<T, float>::value);
+    const bool again = run_task<T, K, MODE>(B, task, lds + wave * B.lds_per_wave, lane, std::is_same<T, float>::value);
+    // Up to kInlineRerunRows rows per lane (the values region-sized calls take) the wave redoes its work item in fp64
+    // itself instead of leaving it to a launch of fwd_list: on a call whose time is the chain of its launches that
+    // launch, empty almost always, is 4 us.  The item still goes on the list, which the host reads for its statistics.
+    if constexpr (std::is_same<T, float>::value && K <= kInlineRerunRows) {
+        if (again) {
+            __builtin_amdgcn_wave_barrier();
+            constexpr int kMode64 = (MODE == kEmitLut5 || MODE == kEmitCompareN) ? kEmitCompareN : kEmitCompare;
+            run_task<double, K, kMode64>(B, task, lds + wave * B.lds_per_wave, lane, false);
+        }
+    }
 }
 
 // Tasks taken from the device-side rerun list; every wave strides over the list, so the grid
