@@ -302,6 +302,7 @@ struct gatk_pairhmm {
     hipStream_t stream = nullptr;
     int wave_slots = 3072;  // waves the device holds at once at three per SIMD
     size_t kernel_upload_bytes = size_t{1} << 20;  // uploads up to this size are copied by a kernel, not by the DMA engine
+    size_t kernel_download_bytes = size_t{512} << 10;  // results of at most this many bytes are copied back by a kernel
     int64_t per_group_factor = 32;  // calls with at least this many pairs per wave slot choose rows per lane per wave-group
     bool combine_calls = false;  // small compute_likelihoods calls of all threads on this device share device passes
     bool pipeline_ramp = true;  // the first two parts of a cut call are a quarter and a half of pipeline_pairs
@@ -1302,7 +1303,13 @@ int download_into(gatk_pairhmm* h, gatk_pairhmm_resident* R, double* const* outs
     // counters and likelihoods in one device-to-host copy into pinned memory, one wait, then scatter on the host
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(h->stage_out.ensure(kCounterBytes + bytes));
-    HIP_TRY(hipMemcpyAsync(h->stage_out.p, R->d_out.p, kCounterBytes + bytes, hipMemcpyDeviceToHost, R->stream));
+    // A small result goes home through a kernel on the compute stream (the copy kernel of the uploads, device to pinned
+    // host memory): the runtime's own copy starts 5-6 us after the kernel in front of it, a kernel follows a kernel at once.
+    const size_t down_bytes = (kCounterBytes + bytes + 255) & ~size_t{255};
+    if (down_bytes <= h->kernel_download_bytes && down_bytes <= h->stage_out.cap && down_bytes <= R->d_out.cap)
+        HIP_TRY(launch_upload(R->d_out.p, h->stage_out.p, down_bytes, R->stream));
+    else
+        HIP_TRY(hipMemcpyAsync(h->stage_out.p, R->d_out.p, kCounterBytes + bytes, hipMemcpyDeviceToHost, R->stream));
     // the host waits for the copy only; the counters are zeroed for the next pass behind it
     if (!R->ev_downloaded) HIP_TRY(hipEventCreateWithFlags(&R->ev_downloaded, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(R->ev_downloaded, R->stream));
@@ -2064,6 +2071,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
     else if (n == "pipeline_min_pairs") h->pipeline_min_pairs = std::max<int64_t>(1, static_cast<int64_t>(value));
     else if (n == "combine_calls") h->combine_calls = value != 0;
     else if (n == "per_group_factor") h->per_group_factor = std::max<int64_t>(1, static_cast<int64_t>(value));
+    else if (n == "kernel_download_bytes") h->kernel_download_bytes = static_cast<size_t>(std::max(0.0, value));
     else if (n == "kernel_upload_bytes") h->kernel_upload_bytes = static_cast<size_t>(std::max(0.0, value));
     else if (n == "wave_slots") h->wave_slots = std::max(64, static_cast<int>(value));
     else if (n == "stream_lds_floor") h->stream_lds_floor = std::max(0, static_cast<int>(value));

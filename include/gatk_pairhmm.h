@@ -208,6 +208,9 @@ int gatk_pairhmm_device_count(int32_t* count);
  *   "kernel_upload_bytes" default 1048576: an upload of at most that many bytes is copied out of the pinned
  *                         staging buffer by a kernel on the compute stream instead of by the DMA engine, whose
  *                         hand-over to the first kernel costs more than the copy of a region-sized call.
+ *   "kernel_download_bytes" default 524288: results of at most that many bytes (counters included) come back through
+ *                         the same kind of kernel, device to pinned host memory: the runtime's copy starts 5-6 us
+ *                         after the kernel in front of it.
  *   "wave_slots"          waves the planner assumes the device holds at once, default 12 per CU (occupancy
  *                         experiments).
  *   "stream_lds_floor"    least bytes of LDS a wave of the fp32 stream pass asks for; a larger value lowers the
