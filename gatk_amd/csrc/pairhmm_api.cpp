@@ -43,6 +43,7 @@ hipError_t launch_marginalize_reads(const DeviceBatch& B, const int32_t* old_to_
                                     double* new_out, hipStream_t stream);
 hipError_t launch_prepare(const DeviceBatch& B, bool expand_rows, bool stream, hipStream_t s);
 hipError_t launch_upload(const void* pinned_host, void* device, size_t bytes, hipStream_t s);
+hipError_t launch_download(void* device, void* pinned_host, size_t bytes, size_t clear_bytes, hipStream_t s);
 }  // namespace pairhmm_hip
 
 using namespace pairhmm_hip;
@@ -1303,17 +1304,18 @@ int download_into(gatk_pairhmm* h, gatk_pairhmm_resident* R, double* const* outs
     // counters and likelihoods in one device-to-host copy into pinned memory, one wait, then scatter on the host
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(h->stage_out.ensure(kCounterBytes + bytes));
-    // A small result goes home through a kernel on the compute stream (the copy kernel of the uploads, device to pinned
-    // host memory): the runtime's own copy starts 5-6 us after the kernel in front of it, a kernel follows a kernel at once.
+    // A small result goes home through a kernel on the compute stream (device to pinned host memory; it zeroes the
+    // counters for the next pass on its way): the runtime's own copy starts 5-6 us after the kernel in front of it, a
+    // kernel follows a kernel at once.
     const size_t down_bytes = (kCounterBytes + bytes + 255) & ~size_t{255};
-    if (down_bytes <= h->kernel_download_bytes && down_bytes <= h->stage_out.cap && down_bytes <= R->d_out.cap)
-        HIP_TRY(launch_upload(R->d_out.p, h->stage_out.p, down_bytes, R->stream));
-    else
-        HIP_TRY(hipMemcpyAsync(h->stage_out.p, R->d_out.p, kCounterBytes + bytes, hipMemcpyDeviceToHost, R->stream));
-    // the host waits for the copy only; the counters are zeroed for the next pass behind it
+    const bool by_kernel = down_bytes <= h->kernel_download_bytes && down_bytes <= h->stage_out.cap && down_bytes <= R->d_out.cap &&
+                           static_cast<void*>(R->counters()) == R->d_out.p;
+    if (by_kernel) HIP_TRY(launch_download(R->d_out.p, h->stage_out.p, down_bytes, kCounterBytes, R->stream));
+    else HIP_TRY(hipMemcpyAsync(h->stage_out.p, R->d_out.p, kCounterBytes + bytes, hipMemcpyDeviceToHost, R->stream));
+    // the host waits for the copy only; the runtime's copy leaves the counters to a memset behind it
     if (!R->ev_downloaded) HIP_TRY(hipEventCreateWithFlags(&R->ev_downloaded, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(R->ev_downloaded, R->stream));
-    HIP_TRY(hipMemsetAsync(R->counters(), 0, kCounterBytes, R->stream));
+    if (!by_kernel) HIP_TRY(hipMemsetAsync(R->counters(), 0, kCounterBytes, R->stream));
     R->counters_clear = true;
     HIP_TRY(hipEventSynchronize(R->ev_downloaded));
     if (int rc = digest_counters(h, R, static_cast<const int32_t*>(h->stage_out.p))) return rc;

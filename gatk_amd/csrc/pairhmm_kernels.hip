@@ -1443,6 +1443,23 @@ hipError_t launch_upload(const void* pinned_host, void* device, size_t bytes, hi
     return hipGetLastError();
 }
 
+// The way back for a small result: counters and likelihoods from the device into pinned host memory, and the first
+// clear16 16-byte words of the source (the counters) zeroed for the next pass, in one launch.
+__global__ void __launch_bounds__(256) download_to_host(uint4* src, uint4* __restrict__ dst, const int n16, const int clear16) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n16; k += gridDim.x * blockDim.x) {
+        dst[k] = src[k];
+        if (k < clear16) src[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+hipError_t launch_download(void* device, void* pinned_host, size_t bytes, size_t clear_bytes, hipStream_t s) {
+    const int n16 = static_cast<int>((bytes + 15) / 16);
+    if (n16 <= 0) return hipSuccess;
+    hipLaunchKernelGGL(download_to_host, dim3(std::min((n16 + 255) / 256, 512)), dim3(256), 0, s,
+                       static_cast<uint4*>(device), static_cast<uint4*>(pinned_host), n16, static_cast<int>(clear_bytes / 16));
+    return hipGetLastError();
+}
+
 // expand_rows: write the RowConst entries (the fp32 passes read them); stream: fill the haplotype stream.
 hipError_t launch_prepare(const DeviceBatch& B, bool expand_rows, bool stream, hipStream_t s) {
     const int read_blocks = (B.num_reads + 3) / 4;
