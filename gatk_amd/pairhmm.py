@@ -243,12 +243,18 @@ class PreparedRegions:
     one flat output buffer.  compute() is then the C-ABI call alone, as a host that already holds its arrays (the
     Java side) would make it."""
 
-    def __init__(self, hmm, regions):
+    def __init__(self, hmm, regions, flat=None):
+        """flat: a float64 buffer of exactly the call's size to score into (e.g. this rank's slice of a shared-memory
+        segment, sharding.SharedOutput), or None for a buffer of its own."""
         self.hmm, self.regions, self._keep = hmm, list(regions), []
         n = len(self.regions)
         self._cbs = (CBatch * max(1, n))(*[to_cbatch(b, self._keep) for b in self.regions])
         sizes = [b.num_reads * b.num_haps for b in self.regions]
-        self.flat = np.full(int(sum(sizes)), np.nan, dtype=np.float64)
+        if flat is None:
+            flat = np.full(int(sum(sizes)), np.nan, dtype=np.float64)
+        if flat.dtype != np.float64 or flat.ndim != 1 or flat.size != int(sum(sizes)) or not flat.flags.c_contiguous:
+            raise ValueError("flat must be a contiguous float64 vector with one entry per (read, haplotype) pair of the call")
+        self.flat = flat
         self.outs = RegionResults()
         off = 0
         for b, size in zip(self.regions, sizes):
@@ -314,8 +320,8 @@ class HipLoglessPairHMM:
         _check(self._lib.gatk_pairhmm_compute_likelihoods_noalloc(self._h, stream, C.byref(cbatch), read_max_length,
                                                                   haplotype_max_length, out_ptr, status_ptr))
 
-    def prepare_regions(self, regions) -> PreparedRegions:
-        return PreparedRegions(self, regions)
+    def prepare_regions(self, regions, flat=None) -> PreparedRegions:
+        return PreparedRegions(self, regions, flat)
 
     def upload(self, regions) -> Resident:
         keep = []

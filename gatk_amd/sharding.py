@@ -4,7 +4,8 @@ Every (read, haplotype) pair is independent (PairHMM.java:217,284 force a full r
 pair) and so is every active region (TraverseActiveRegions.java:705-709 maps them one by one),
 so the unit of distribution is the region batch, or a read range of one very large batch.  Each
 rank scores its share on its own GPU; the likelihood arrays are then gathered on the host of
-rank 0 (a gloo gather of CPU arrays).  Nothing is exchanged between GPUs.  A host that is one process
+rank 0: a gloo gather of CPU arrays, or - the ranks of one node - every rank's results written straight into its
+slice of one shared-memory segment (SharedOutput), where the gather is a barrier.  Nothing is exchanged between GPUs.  A host that is one process
 uses the multi-device handle of the C-ABI instead (gatk_pairhmm_create_multi), which shards the same way
 inside the library and needs no gather.
 """
@@ -66,7 +67,62 @@ def _gather_flat(flat, sizes, rank, world, group):
     return [recv[r].numpy()[:sizes[r]] for r in range(world)]
 
 
-def compute_sharded(regions, compute_fn, rank=0, world=1, gather_group=None, shards=None):
+class SharedOutput:
+    """One shared-memory segment for the likelihoods of a whole region list, for ranks that run on one host: rank r's
+    share of the list (shards[r], in that order) occupies a contiguous slice, `mine` is this rank's, and a
+    compute_sharded call that is given the object only has to wait at a barrier: every device's results are copied D2H
+    into their place in the output, and nothing is gathered afterwards.  Collective: every rank of `group` (a gloo
+    group) constructs it with the same regions and shards."""
+
+    def __init__(self, regions, shards, rank, world, group=None):
+        from multiprocessing import resource_tracker, shared_memory
+
+        import torch.distributed as dist
+
+        self.rank, self.world, self.group = rank, world, group
+        self.sizes = [sum(regions[i].num_reads * regions[i].num_haps for i in s) for s in shards]
+        self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
+        total = int(self.offsets[-1])
+        name = [None]
+        if rank == 0:
+            self._shm = shared_memory.SharedMemory(create=True, size=max(8, total * 8))
+            name[0] = self._shm.name
+        dist.broadcast_object_list(name, src=0, group=group)
+        if rank != 0:
+            self._shm = shared_memory.SharedMemory(name=name[0])
+            # the segment belongs to rank 0: this process's resource tracker must not remove it at exit
+            try:
+                resource_tracker.unregister(self._shm._name, "shared_memory")
+            except Exception:
+                pass
+        self.flat = np.ndarray((total,), dtype=np.float64, buffer=self._shm.buf)
+        self.mine = self.flat[int(self.offsets[rank]):int(self.offsets[rank + 1])]
+        dist.barrier(group=group)
+
+    def views(self, regions, shards):
+        """The per-region [reads, haps] views in input order (meaningful on every rank once all have written)."""
+        result = [None] * len(regions)
+        for r in range(self.world):
+            off = int(self.offsets[r])
+            for i in shards[r]:
+                b = regions[i]
+                n = b.num_reads * b.num_haps
+                result[i] = self.flat[off:off + n].reshape(b.num_reads, b.num_haps)
+                off += n
+        return result
+
+    def close(self):
+        """Collective: no rank may still hold views into the segment."""
+        import torch.distributed as dist
+
+        dist.barrier(group=self.group)
+        self.flat = self.mine = None
+        self._shm.close()
+        if self.rank == 0:
+            self._shm.unlink()
+
+
+def compute_sharded(regions, compute_fn, rank=0, world=1, gather_group=None, shards=None, shared=None):
     """Score `regions` (list of Batch) with `compute_fn(list_of_batches) -> list of [reads, haps]
     arrays` on this rank's share and gather on rank 0.
 
@@ -74,7 +130,9 @@ def compute_sharded(regions, compute_fn, rank=0, world=1, gather_group=None, sha
     world == 1 no process group is touched.  gather_group must be a CPU (gloo) group: the gather
     is a host-side copy, not a GPU collective.  `shards` (the result of shard_regions for this list and
     world) may be passed by a caller that scores the same list more than once.  A compute_fn whose result
-    carries the arrays as consecutive views of one buffer (attribute `flat_buffer`) is gathered without a copy."""
+    carries the arrays as consecutive views of one buffer (attribute `flat_buffer`) is gathered without a copy.
+    `shared` (a SharedOutput made for this list and these shards): the results go into this rank's slice of the shared
+    segment - nothing to do when compute_fn scored into it already - and the gather is a barrier."""
     if shards is None:
         shards = shard_regions(regions, world)
     mine = shards[rank]
@@ -82,6 +140,18 @@ def compute_sharded(regions, compute_fn, rank=0, world=1, gather_group=None, sha
     if world == 1:
         return list(outs)
     flat = getattr(outs, "flat_buffer", None)
+    if shared is not None:
+        import torch.distributed as dist
+
+        if flat is None or flat.size == 0 or flat.__array_interface__["data"][0] != shared.mine.__array_interface__["data"][0]:
+            off = 0
+            for o in outs:
+                o = np.asarray(o, dtype=np.float64).reshape(-1)
+                shared.mine[off:off + o.size] = o
+                off += o.size
+            assert off == shared.mine.size
+        dist.barrier(group=gather_group)
+        return shared.views(regions, shards) if rank == 0 else None
     if flat is None:
         flat = np.concatenate([np.asarray(o, dtype=np.float64).reshape(-1) for o in outs]) if outs else np.zeros(0)
     sizes = [sum(regions[i].num_reads * regions[i].num_haps for i in s) for s in shards]

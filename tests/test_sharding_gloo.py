@@ -1,5 +1,5 @@
 """The N > 1 path on CPU: two processes (gloo) each score their share of a region stream and of
-one large batch, rank 0 gathers on the host.  The per-rank compute is the CPU oracle here (no
+one large batch, rank 0 gathers on the host (gloo gather, and the shared-memory output of a single node).  The per-rank compute is the CPU oracle here (no
 GPU in this tier); on the GPU box the same functions are driven with the HIP engine
 (tests/test_gpu_parity.py::test_sharded_regions_single_rank)."""
 import os
@@ -37,10 +37,18 @@ def _worker(rank, world, port, q):
         got = sharding.compute_sharded(regions, _oracle_compute, rank, world)
         big = synth.make_batch(23, 3, 40, 90, seed=22, len_jitter=15)
         whole = sharding.compute_split_batch(big, _oracle_compute, rank, world)
+        # the same list through the shared-memory output of a single node: the gather is a barrier
+        shards = sharding.shard_regions(regions, world)
+        shared = sharding.SharedOutput(regions, shards, rank, world)
+        try:
+            via_shm = sharding.compute_sharded(regions, _oracle_compute, rank, world, shards=shards, shared=shared)
+            via_shm = [np.array(v) for v in via_shm] if rank == 0 else None  # copies: the segment goes away below
+        finally:
+            shared.close()
         if rank == 0:
-            q.put((got, whole))
+            q.put((got, whole, via_shm))
         else:
-            assert got is None and whole is None
+            assert got is None and whole is None and via_shm is None
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -53,15 +61,16 @@ def test_two_rank_sharding_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got, whole = q.get(timeout=120)
+    got, whole, via_shm = q.get(timeout=120)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     regions = synth.make_regions(9, seed=21, coverage=6, read_len=60)
     want = _oracle_compute(regions)
     assert len(got) == len(want)
-    for g, w in zip(got, want):
+    for g, w, v in zip(got, want, via_shm):
         np.testing.assert_array_equal(g, w)
+        np.testing.assert_array_equal(v, w)
     big = synth.make_batch(23, 3, 40, 90, seed=22, len_jitter=15)
     np.testing.assert_array_equal(whole, _oracle_compute([big])[0])
     # both ranks had work
