@@ -322,6 +322,26 @@ def test_sharded_regions_single_rank(hmm, oracle):
     assert_parity(sharding.compute_split_batch(big, hmm.compute_regions), ref(oracle, big))
 
 
+def test_prepared_call_scores_into_a_given_buffer(hmm):
+    """prepare_regions marshals a compute_regions call once; with flat= it scores into the caller's buffer (the
+    slice of a shared-memory segment when processes shard a list, sharding.SharedOutput)."""
+    regions = synth.make_regions(7, seed=33, coverage=8, read_len=100)
+    want = hmm.compute_regions(regions)
+    total = sum(b.num_reads * b.num_haps for b in regions)
+    buf = np.full(total + 3, -7.0)
+    call = hmm.prepare_regions(regions, flat=buf[1:1 + total])
+    for _ in range(2):
+        outs = call.compute()
+        for o, w in zip(outs, want):
+            np.testing.assert_array_equal(o, w)
+    assert buf[0] == -7.0 and (buf[1 + total:] == -7.0).all()  # nothing outside the slice
+    assert np.array_equal(buf[1:1 + total], np.concatenate([w.reshape(-1) for w in want]))
+    own = hmm.prepare_regions(regions).compute()
+    assert all(np.array_equal(o, w) for o, w in zip(own, want))
+    with pytest.raises(ValueError):
+        hmm.prepare_regions(regions, flat=np.zeros(total + 1))
+
+
 def test_long_haplotype_and_length_cap(hmm, oracle):
     rng = np.random.default_rng(6)
     acgt = np.frombuffer(b"ACGT", np.uint8)
