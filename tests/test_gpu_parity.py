@@ -491,6 +491,16 @@ def test_haplotype_runs_of_every_length(hmm, oracle, run):
     assert_parity(got, want)
 
 
+@pytest.mark.parametrize("num_haps,num_reads", [(200, 50), (513, 7)])
+def test_regions_with_hundreds_of_haplotypes(hmm, oracle, num_haps, num_reads):
+    # far more haplotypes than the assembler's cap per region (128 per k-mer size)
+    b = synth.make_batch(num_reads, num_haps, 80, 200, seed=num_haps, len_jitter=20)
+    want = ref(oracle, b)
+    for mode in (-1, 1, 0):
+        got = with_options(hmm, {"stream_mode": mode}, lambda: hmm.compute_batch(b))
+        assert_parity(got, want)
+
+
 def test_runs_and_single_haplotype_items_agree(hmm, oracle):
     b = synth.make_batch(300, 40, 151, 420, seed=77, len_jitter=30, hap_len_jitter=60)
     runs = hmm.compute_batch(b)
