@@ -38,6 +38,7 @@ constexpr int kHeadElems = 16;  // raw CIGAR elements of a pair that come back w
 constexpr int kNumRowChoices = 13;
 constexpr int kRowChoices[kNumRowChoices] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 24, 32};  // rows per lane a fill kernel exists for
 constexpr int kMaxAlt = 16000;
+constexpr size_t kStagedPoolBytes = 1 << 20;      // sequence pools from this size on go up one launch at a time
 constexpr int kLowInit = INT_MIN / 2;             // lowInitValue, :235
 constexpr int kMatrixMinCutoff = -100000000;      // (int) -1e8, :233 (the static cutoff flag is false)
 
@@ -285,6 +286,10 @@ struct Scratch {
     size_t cap = 0;
     hipStream_t main = nullptr, side[kSideStreams] = {};
     hipEvent_t fork = nullptr, join[kSideStreams] = {};
+    void* up = nullptr;    // pinned host staging of what a call sends ...
+    size_t up_cap = 0;
+    void* down = nullptr;  // ... and of what comes back with the first copy
+    size_t down_cap = 0;
 };
 thread_local std::vector<Scratch> g_scratch;
 
@@ -315,6 +320,16 @@ hipError_t scratch_for(int device, size_t bytes, void** out, Scratch** scratch) 
     }
     *out = s->p;
     return hipSuccess;
+}
+
+// Grow-only pinned host buffer (contents are not kept).
+hipError_t pinned_for(void** p, size_t* cap, size_t bytes) {
+    if (bytes <= *cap) return hipSuccess;
+    if (*p) { hipError_t e = hipHostFree(*p); *p = nullptr; *cap = 0; if (e != hipSuccess) return e; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(p, want, hipHostMallocDefault);
+    if (e == hipSuccess) *cap = want;
+    return e;
 }
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -361,8 +376,6 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
                                                       std::to_string(kMaxAlt) + " bases (pair " + std::to_string(k) + ")");
         PairDesc& P = pairs[k];
         P.n = n; P.m = m;
-        P.ref_off = static_cast<int64_t>(pool_bytes); pool_bytes += align_up(n, 16);
-        P.alt_off = static_cast<int64_t>(pool_bytes); pool_bytes += align_up(m, 16);
         P.edge_off = static_cast<int64_t>(edge_ints); edge_ints += static_cast<size_t>(n + 1) + (m + 1);
         // an element is added when the back-track changes state, plus a few at the ends: a list that outgrows
         // this cannot consolidate into cigar_capacity elements
@@ -393,20 +406,24 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
         std::array<int, kNumRowChoices> at{};
         for (int k = 0; k < num_pairs; ++k) order[group_begin[choice[k]] + at[choice[k]]++] = k;
     }
+    // the sequence pool in launch order (most rows per lane first), so that a launch's sequences are one range of it
+    std::array<size_t, kNumRowChoices + 1> group_pool{};  // group c's sequences: [group_pool[c + 1], group_pool[c])
+    for (int c = kNumRowChoices - 1; c >= 0; --c) {
+        group_pool[c + 1] = pool_bytes;
+        for (int x = group_begin[c]; x < group_begin[c + 1]; ++x) {
+            PairDesc& P = pairs[order[x]];
+            P.ref_off = static_cast<int64_t>(pool_bytes); pool_bytes += align_up(P.n, 16);
+            P.alt_off = static_cast<int64_t>(pool_bytes); pool_bytes += align_up(P.m, 16);
+        }
+    }
+    group_pool[0] = pool_bytes;
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t at = off; off = align_up(off + bytes, 256); return at; };
-    const size_t o_pool = carve(pool_bytes), o_pairs = carve(pairs.size() * sizeof(PairDesc)), o_order = carve(order.size() * sizeof(int32_t));
+    const size_t o_pairs = carve(pairs.size() * sizeof(PairDesc)), o_order = carve(order.size() * sizeof(int32_t)), o_pool = carve(pool_bytes);
     const size_t upload_bytes = off;
     const size_t o_bt = carve(bt_entries * sizeof(int16_t)), o_edges = carve(edge_ints * sizeof(int32_t)),
                  o_elems = carve(elem_ints * sizeof(int32_t)), o_results = carve(pairs.size() * sizeof(PairResult)),
                  o_heads = carve(pairs.size() * 2 * kHeadElems * sizeof(int32_t));
-    std::vector<uint8_t> host(upload_bytes, 0);
-    for (int k = 0; k < num_pairs; ++k) {
-        memcpy(host.data() + o_pool + pairs[k].ref_off, references[k], pairs[k].n);
-        memcpy(host.data() + o_pool + pairs[k].alt_off, alternates[k], pairs[k].m);
-    }
-    memcpy(host.data() + o_pairs, pairs.data(), pairs.size() * sizeof(PairDesc));
-    memcpy(host.data() + o_order, order.data(), order.size() * sizeof(int32_t));
 
     // ---- device -----------------------------------------------------------------------------------
     SW_TRY(hipSetDevice(device));
@@ -415,7 +432,24 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
     SW_TRY(scratch_for(device, off, &base, &sc));
     uint8_t* D = static_cast<uint8_t*>(base);
     hipStream_t stream = sc->main;  // this thread's stream on the device: its calls are ordered, results are fetched synchronously
-    SW_TRY(hipMemcpyAsync(D, host.data(), upload_bytes, hipMemcpyHostToDevice, stream));
+    // The sequences go straight into pinned memory (the bytes between them are never read).  A large pool goes
+    // up launch by launch on the launch's own stream, so that the host packs the next launch's sequences while
+    // the first one runs; a small one goes up whole with the descriptors.
+    SW_TRY(pinned_for(&sc->up, &sc->up_cap, upload_bytes));
+    uint8_t* host = static_cast<uint8_t*>(sc->up);
+    const bool staged = pool_bytes >= kStagedPoolBytes;
+    auto pack = [&](int c) {
+        for (int x = group_begin[c]; x < group_begin[c + 1]; ++x) {
+            const int k = order[x];
+            memcpy(host + o_pool + pairs[k].ref_off, references[k], pairs[k].n);
+            memcpy(host + o_pool + pairs[k].alt_off, alternates[k], pairs[k].m);
+        }
+    };
+    memcpy(host + o_pairs, pairs.data(), pairs.size() * sizeof(PairDesc));
+    memcpy(host + o_order, order.data(), order.size() * sizeof(int32_t));
+    if (!staged)
+        for (int c = 0; c < kNumRowChoices; ++c) pack(c);
+    SW_TRY(hipMemcpyAsync(D, host, staged ? o_pool : upload_bytes, hipMemcpyHostToDevice, stream));
     SwArgs A{};
     A.pool = D + o_pool;
     A.pairs = reinterpret_cast<const PairDesc*>(D + o_pairs);
@@ -443,6 +477,11 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
             side_used[k] = true;
         }
         ++launches;
+        if (staged) {
+            pack(c);
+            SW_TRY(hipMemcpyAsync(D + o_pool + group_pool[c + 1], host + o_pool + group_pool[c + 1], group_pool[c] - group_pool[c + 1],
+                                  hipMemcpyHostToDevice, stream));
+        }
         hipError_t e = hipErrorInvalidValue;
         switch (kRowChoices[c]) {
             case 1: e = launch_fill<1>(A, first, count, lds, stream); break;
@@ -469,14 +508,16 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
     // one back-track launch behind all fills (run next to them it slows them more than it gains)
     hipLaunchKernelGGL(sw_backtrack, dim3((num_pairs + 63) / 64), dim3(64), 0, stream, A, 0, num_pairs);
     SW_TRY(hipGetLastError());
-    std::vector<PairResult> results(num_pairs);
     // Raw element lists: alignments of haplotypes have a handful of elements, so the first kHeadElems of every
     // pair come back packed in one copy and the rest of the few longer lists afterwards.
     const int head = std::min(kHeadElems, elem_stride);
-    std::vector<int32_t> heads(static_cast<size_t>(num_pairs) * 2 * kHeadElems);
-    SW_TRY(hipMemcpyAsync(results.data(), D + o_results, results.size() * sizeof(PairResult), hipMemcpyDeviceToHost, stream));
-    SW_TRY(hipMemcpyAsync(heads.data(), D + o_heads, heads.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    const size_t results_bytes = align_up(pairs.size() * sizeof(PairResult), 256), heads_bytes = pairs.size() * 2 * kHeadElems * sizeof(int32_t);
+    static_assert(sizeof(PairResult) == 8, "results and heads come back in one copy");
+    SW_TRY(pinned_for(&sc->down, &sc->down_cap, results_bytes + heads_bytes));
+    SW_TRY(hipMemcpyAsync(sc->down, D + o_results, results_bytes + heads_bytes, hipMemcpyDeviceToHost, stream));  // o_heads follows o_results
     SW_TRY(hipStreamSynchronize(stream));
+    const PairResult* results = static_cast<const PairResult*>(sc->down);
+    const int32_t* heads = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(sc->down) + results_bytes);
     std::vector<int32_t> tails;                          // elements head.. of the pairs that have them, back to back
     std::vector<int64_t> tail_at(num_pairs, -1);         // a pair's offset in tails
     {
@@ -500,7 +541,7 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
     // ---- Collections.reverse + AlignmentUtils.consolidateCigar (sam/AlignmentUtils.java:698-727) -------
     int rc = GATK_SW_OK;
     for (int k = 0; k < num_pairs; ++k) {
-        const int32_t* raw_head = heads.data() + static_cast<size_t>(k) * 2 * kHeadElems;
+        const int32_t* raw_head = heads + static_cast<size_t>(k) * 2 * kHeadElems;
         const int32_t* raw_tail = tail_at[k] >= 0 ? tails.data() + tail_at[k] : nullptr;
         if (results[k].num_elems > pairs[k].elem_cap)
             rc = fail(GATK_SW_CIGAR_TOO_LONG, "pair " + std::to_string(k) + " needs more than cigar_capacity elements");
