@@ -17,6 +17,8 @@
 #include <deque>
 #include <map>
 #include <memory>
+#include <new>
+#include <stdexcept>
 #include <mutex>
 #include <cstdio>
 #include <cstring>
@@ -95,6 +97,19 @@ struct RegionCallCount {
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
+}
+
+// The handler of every entry point: no C++ exception (a failed host allocation, a thread that cannot be
+// started) crosses the C boundary into a caller that cannot unwind it.
+int on_exception() noexcept {
+    try {
+        try { throw; }
+        catch (const std::bad_alloc&) { return fail(GATK_PAIRHMM_OUT_OF_MEMORY, "host memory exhausted"); }
+        catch (const std::exception& e) { return fail(GATK_PAIRHMM_DEVICE_ERROR, std::string("internal error: ") + e.what()); }
+        catch (...) { return fail(GATK_PAIRHMM_DEVICE_ERROR, "internal error: unknown exception"); }
+    } catch (...) {
+        return GATK_PAIRHMM_OUT_OF_MEMORY;  // not even the message could be stored
+    }
 }
 
 #define HIP_TRY(expr)                                                                                   \
@@ -1352,20 +1367,20 @@ extern "C" {
 const char* gatk_pairhmm_last_error(void) { return g_last_error.c_str(); }
 const char* gatk_pairhmm_version(void) { return "gatk_pairhmm_hip 0.1 (gfx950)"; }
 
-int gatk_pairhmm_device_count(int32_t* count) {
+int gatk_pairhmm_device_count(int32_t* count) try {
     if (!count) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "count cannot be null");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
     *count = n;
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_set_number_of_threads(int32_t num_threads) {
+int gatk_pairhmm_set_number_of_threads(int32_t num_threads) try {
     g_num_threads.store(num_threads);
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_create(int device, gatk_pairhmm** out) {
+int gatk_pairhmm_create(int device, gatk_pairhmm** out) try {
     if (!out) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "out cannot be null");
     *out = nullptr;
     int n = 0;
@@ -1406,9 +1421,9 @@ int gatk_pairhmm_create(int device, gatk_pairhmm** out) {
     g_live_handles.fetch_add(1);
     *out = h;
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_initialize(gatk_pairhmm* h, int32_t read_max_length, int32_t haplotype_max_length) {
+int gatk_pairhmm_initialize(gatk_pairhmm* h, int32_t read_max_length, int32_t haplotype_max_length) try {
     if (int rc = check_handle(h)) return rc;
     if (read_max_length <= 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "READ_MAX_LENGTH must be > 0 but got " + std::to_string(read_max_length));
     if (haplotype_max_length <= 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "HAPLOTYPE_MAX_LENGTH must be > 0 but got " + std::to_string(haplotype_max_length));
@@ -1417,7 +1432,7 @@ int gatk_pairhmm_initialize(gatk_pairhmm* h, int32_t read_max_length, int32_t ha
     h->initialized = true;
     for (gatk_pairhmm* c : h->children) { c->max_read = read_max_length; c->max_hap = haplotype_max_length; c->initialized = true; }
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
 static int compute_regions_multi(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions, double* const* likelihoods);
 
@@ -1561,14 +1576,14 @@ static int compute_regions_single(gatk_pairhmm* h, int32_t num_regions, const ga
 }
 
 int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
-                                 double* const* likelihoods) {
+                                 double* const* likelihoods) try {
     if (int rc = check_handle(h)) return rc;
     if (num_regions < 0 || (num_regions > 0 && !regions)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "regions cannot be null");
     if (!h->children.empty()) return compute_regions_multi(h, num_regions, regions, likelihoods);
     return compute_regions_single(h, num_regions, regions, likelihoods, false);
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_create_multi(const int32_t* devices, int32_t num_devices, gatk_pairhmm** out) {
+int gatk_pairhmm_create_multi(const int32_t* devices, int32_t num_devices, gatk_pairhmm** out) try {
     if (!out) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "out cannot be null");
     *out = nullptr;
     std::vector<int> list;
@@ -1597,7 +1612,7 @@ int gatk_pairhmm_create_multi(const int32_t* devices, int32_t num_devices, gatk_
     }
     *out = h;
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
 // compute_regions on a multi-device handle: the regions go to the engines longest-processing-time first by cell
 // count (sum of readLen * hapLen), a region worth more than half a device's share is cut by read ranges first
@@ -1872,7 +1887,7 @@ int compute_combined(int device, bool squash, const gatk_pairhmm_batch* batch, d
 
 }  // namespace
 
-int gatk_pairhmm_compute_likelihoods(gatk_pairhmm* h, const gatk_pairhmm_batch* batch, double* likelihoods) {
+int gatk_pairhmm_compute_likelihoods(gatk_pairhmm* h, const gatk_pairhmm_batch* batch, double* likelihoods) try {
     if (int rc = check_handle(h)) return rc;
     if (!batch) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "batch cannot be null");
     if (batch->num_reads == 0) return GATK_PAIRHMM_OK;  // PairHMM.java:193
@@ -1892,14 +1907,14 @@ int gatk_pairhmm_compute_likelihoods(gatk_pairhmm* h, const gatk_pairhmm_batch* 
     } else if (int rc = gatk_pairhmm_compute_regions(h, 1, batch, outs)) return rc;
     h->likelihood_array.assign(likelihoods, likelihoods + n);  // mLikelihoodArray, PairHMM.java:206,225
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
 int gatk_pairhmm_compute_likelihoods_ptrs(gatk_pairhmm* h, int32_t num_reads, int32_t num_haps,
                                           const uint8_t* const* read_bases, const uint8_t* const* read_quals,
                                           const uint8_t* const* ins_gop, const uint8_t* const* del_gop,
                                           const uint8_t* const* gcp, const int32_t* read_lengths,
                                           const uint8_t* const* hap_bases, const int32_t* hap_lengths,
-                                          double* likelihoods) {
+                                          double* likelihoods) try {
     if (int rc = check_handle(h)) return rc;
     if (num_reads == 0) return GATK_PAIRHMM_OK;
     if (num_reads < 0 || num_haps < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "negative read or haplotype count");
@@ -1930,11 +1945,11 @@ int gatk_pairhmm_compute_likelihoods_ptrs(gatk_pairhmm* h, int32_t num_reads, in
     rb.push_back(0); rq.push_back(0); ri.push_back(0); rd.push_back(0); rg.push_back(0); hb.push_back(0);
     gatk_pairhmm_batch b{num_reads, num_haps, rb.data(), rq.data(), ri.data(), rd.data(), rg.data(), ro.data(), hb.data(), ho.data()};
     return gatk_pairhmm_compute_likelihoods(h, &b, likelihoods);
-}
+} catch (...) { return on_exception(); }
 
 int gatk_pairhmm_compute_pair(gatk_pairhmm* h, const uint8_t* hap_bases, int32_t hap_length,
                               const uint8_t* read_bases, const uint8_t* read_quals, const uint8_t* ins_gop,
-                              const uint8_t* del_gop, const uint8_t* gcp, int32_t read_length, double* likelihood) {
+                              const uint8_t* del_gop, const uint8_t* gcp, int32_t read_length, double* likelihood) try {
     if (int rc = check_handle(h)) return rc;
     // PairHMM.java:271-279
     if (!h->initialized) return fail(GATK_PAIRHMM_ILLEGAL_STATE, "Must call initialize before calling computeReadLikelihoodGivenHaplotypeLog10");
@@ -1949,11 +1964,11 @@ int gatk_pairhmm_compute_pair(gatk_pairhmm* h, const uint8_t* hap_bases, int32_t
     gatk_pairhmm_batch b{1, 1, read_bases, read_quals, ins_gop, del_gop, gcp, ro, hap_bases, ho};
     double* outs[1] = {likelihood};
     return gatk_pairhmm_compute_regions(h, 1, &b, outs);
-}
+} catch (...) { return on_exception(); }
 
 int gatk_pairhmm_batch_add(gatk_pairhmm* h, int32_t num_haps, const uint8_t* const* hap_bases,
                            const int32_t* hap_lengths, const uint8_t* read_bases, const uint8_t* read_quals,
-                           const uint8_t* ins_gop, const uint8_t* del_gop, const uint8_t* gcp, int32_t read_length) {
+                           const uint8_t* ins_gop, const uint8_t* del_gop, const uint8_t* gcp, int32_t read_length) try {
     if (int rc = check_handle(h)) return rc;
     if (num_haps < 0 || read_length < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "negative count");
     if (!read_bases || !read_quals || !ins_gop || !del_gop || !gcp) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "readBases cannot be null");
@@ -1973,9 +1988,9 @@ int gatk_pairhmm_batch_add(gatk_pairhmm* h, int32_t num_haps, const uint8_t* con
     for (auto* v : {&q.bases, &q.quals, &q.ins, &q.del, &q.gcp, &q.haps}) v->push_back(0);
     h->queue.push_back(std::move(q));
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_batch_get_result(gatk_pairhmm* h, const double** results, int64_t* count) {
+int gatk_pairhmm_batch_get_result(gatk_pairhmm* h, const double** results, int64_t* count) try {
     if (int rc = check_handle(h)) return rc;
     if (!results || !count) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "results cannot be null");
     const size_t n = h->queue.size();
@@ -2000,23 +2015,23 @@ int gatk_pairhmm_batch_get_result(gatk_pairhmm* h, const double** results, int64
     *results = h->queue_results.data();
     *count = total;
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_get_likelihood_array(gatk_pairhmm* h, const double** array, int64_t* count) {
+int gatk_pairhmm_get_likelihood_array(gatk_pairhmm* h, const double** array, int64_t* count) try {
     if (int rc = check_handle(h)) return rc;
     if (!array || !count) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "array cannot be null");
     *array = h->likelihood_array.data();
     *count = static_cast<int64_t>(h->likelihood_array.size());
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_finalize_region(gatk_pairhmm* h) {
+int gatk_pairhmm_finalize_region(gatk_pairhmm* h) try {
     if (int rc = check_handle(h)) return rc;
     h->queue.clear();
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_close(gatk_pairhmm* h) {
+int gatk_pairhmm_close(gatk_pairhmm* h) try {
     if (!h) return GATK_PAIRHMM_OK;
     if (!h->children.empty() || !h->workers.empty()) {  // a multi-device handle owns engines and threads only
         for (auto& w : h->workers) w->shutdown();
@@ -2042,16 +2057,16 @@ int gatk_pairhmm_close(gatk_pairhmm* h) {
     if (h->stream3) (void)hipStreamDestroy(h->stream3);
     delete h;
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_get_stats(gatk_pairhmm* h, gatk_pairhmm_stats* out) {
+int gatk_pairhmm_get_stats(gatk_pairhmm* h, gatk_pairhmm_stats* out) try {
     if (int rc = check_handle(h)) return rc;
     if (!out) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "out cannot be null");
     *out = (!h->children.empty() && h->stats_in_first_engine) ? h->children[0]->stats : h->stats;
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
+int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) try {
     if (int rc = check_handle(h)) return rc;
     if (!name) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "name cannot be null");
     const std::string n(name);
@@ -2080,10 +2095,10 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) {
     else if (n == "max_stream_haps") h->max_stream_haps = std::max(1, static_cast<int>(value));
     else return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "unknown option " + n);
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
 int gatk_pairhmm_upload(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
-                        gatk_pairhmm_resident** out) {
+                        gatk_pairhmm_resident** out) try {
     if (int rc = check_handle(h)) return rc;
     h = first_engine(h);
     if (!out) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "out cannot be null");
@@ -2096,9 +2111,9 @@ int gatk_pairhmm_upload(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm
     }
     *out = R;
     return record_stage_in_event(h);  // no pass follows at once
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_compute_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, int32_t sync) {
+int gatk_pairhmm_compute_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, int32_t sync) try {
     if (int rc = check_handle(h)) return rc;
     h = first_engine(h);
     if (!r) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "resident batch cannot be null");
@@ -2106,26 +2121,26 @@ int gatk_pairhmm_compute_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, int
         if (int rc = enqueue_compute(h, r)) return rc;
     if (sync) return finish_compute(h, r);
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_wait_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r) {
+int gatk_pairhmm_wait_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r) try {
     if (int rc = check_handle(h)) return rc;
     h = first_engine(h);
     if (!r) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "resident batch cannot be null");
     if (r->total_pairs == 0) return GATK_PAIRHMM_OK;
     if (!r->computed) return fail(GATK_PAIRHMM_ILLEGAL_STATE, "wait before compute_resident");
     return finish_compute(h, r);
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_download(gatk_pairhmm* h, gatk_pairhmm_resident* r, double* const* likelihoods) {
+int gatk_pairhmm_download(gatk_pairhmm* h, gatk_pairhmm_resident* r, double* const* likelihoods) try {
     if (int rc = check_handle(h)) return rc;
     h = first_engine(h);
     if (!r) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "resident batch cannot be null");
     if (r->total_pairs > 0 && !r->computed) return fail(GATK_PAIRHMM_ILLEGAL_STATE, "download before compute_resident");
     return download_into(h, r, likelihoods);
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_resident_free(gatk_pairhmm* h, gatk_pairhmm_resident* r) {
+int gatk_pairhmm_resident_free(gatk_pairhmm* h, gatk_pairhmm_resident* r) try {
     if (int rc = check_handle(h)) return rc;
     h = first_engine(h);
     if (!r) return GATK_PAIRHMM_OK;
@@ -2134,15 +2149,15 @@ int gatk_pairhmm_resident_free(gatk_pairhmm* h, gatk_pairhmm_resident* r) {
     r->release();
     delete r;
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_get_stream(gatk_pairhmm* h, void** stream) {
+int gatk_pairhmm_get_stream(gatk_pairhmm* h, void** stream) try {
     if (int rc = check_handle(h)) return rc;
     h = first_engine(h);
     if (!stream) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "stream cannot be null");
     *stream = h->stream;
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
 // ---- the steps right behind the path, on results still on the device -----------------------------
 
@@ -2162,7 +2177,7 @@ DeviceBatch epilogue_batch(gatk_pairhmm_resident* r) {
 }  // namespace
 
 int gatk_pairhmm_normalize_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, const int32_t* reference_allele_index,
-                                    int32_t best_to_zero, double maximum_likelihood_difference_cap) {
+                                    int32_t best_to_zero, double maximum_likelihood_difference_cap) try {
     if (int rc = check_epilogue(h, r)) return rc;
     const double cap = maximum_likelihood_difference_cap;
     if (cap >= 0.0 || std::isnan(cap)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "the minimum reference likelihood fall cannot be positive");
@@ -2182,9 +2197,9 @@ int gatk_pairhmm_normalize_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, c
     HIP_TRY(launch_normalize_reads(epilogue_batch(r), d_ref, best_to_zero ? 1 : 0, cap, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));  // reference_allele_index is the caller's memory
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_poorly_modeled_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, double maximum_error_per_base, uint8_t* const* flags) {
+int gatk_pairhmm_poorly_modeled_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, double maximum_error_per_base, uint8_t* const* flags) try {
     if (int rc = check_epilogue(h, r)) return rc;
     if (std::isnan(maximum_error_per_base) || maximum_error_per_base <= 0.0)
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "the maximum error per base must be a positive number");
@@ -2203,10 +2218,10 @@ int gatk_pairhmm_poorly_modeled_resident(gatk_pairhmm* h, gatk_pairhmm_resident*
         memcpy(flags[k], host.data() + r->region_read_begin[k], static_cast<size_t>(r->region_reads[k]));
     }
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
 int gatk_pairhmm_marginalize_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r, const int32_t* const* old_to_new_allele_index,
-                                      const int32_t* new_allele_count, double* const* new_likelihoods) {
+                                      const int32_t* new_allele_count, double* const* new_likelihoods) try {
     if (int rc = check_epilogue(h, r)) return rc;
     if (r->total_pairs == 0) return GATK_PAIRHMM_OK;
     if (!old_to_new_allele_index || !new_allele_count || !new_likelihoods) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "argument cannot be null");
@@ -2252,14 +2267,14 @@ int gatk_pairhmm_marginalize_resident(gatk_pairhmm* h, gatk_pairhmm_resident* r,
         if (n > 0) memcpy(new_likelihoods[k], host.data() + region_new_off[k], static_cast<size_t>(n) * sizeof(double));
     }
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
-int gatk_pairhmm_resident_device_output(gatk_pairhmm_resident* r, void** device_ptr, int64_t* count) {
+int gatk_pairhmm_resident_device_output(gatk_pairhmm_resident* r, void** device_ptr, int64_t* count) try {
     if (!r || !device_ptr || !count) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "argument cannot be null");
     *device_ptr = r->out();
     *count = r->total_pairs;
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 
 }  // extern "C"
 
@@ -2378,7 +2393,7 @@ __global__ void __launch_bounds__(256) noalloc_plan(const NoAllocPlan a) {
 
 extern "C" int gatk_pairhmm_compute_likelihoods_noalloc(gatk_pairhmm* h, void* stream, const gatk_pairhmm_batch* device_batch,
                                                         int32_t read_max_length, int32_t haplotype_max_length,
-                                                        double* device_likelihoods, int32_t* device_status) {
+                                                        double* device_likelihoods, int32_t* device_status) try {
     if (int rc = check_handle(h)) return rc;
     h = first_engine(h);
     const gatk_pairhmm_batch* b = device_batch;
@@ -2461,5 +2476,5 @@ extern "C" int gatk_pairhmm_compute_likelihoods_noalloc(gatk_pairhmm* h, void* s
     if (K > kInlineRerunRows)  // with fewer rows per lane the fp32 pass redoes its underflowing items itself
         HIP_TRY(launch_forward(B, K, kEmitCompareN, true, true, std::min(blocks, 1024), s));
     return GATK_PAIRHMM_OK;
-}
+} catch (...) { return on_exception(); }
 

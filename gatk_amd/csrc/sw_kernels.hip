@@ -24,6 +24,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -349,7 +351,7 @@ const char* gatk_sw_last_error(void) { return g_sw_error.c_str(); }
 int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* references, const int32_t* reference_lengths,
                   const uint8_t* const* alternates, const int32_t* alternate_lengths, const gatk_sw_parameters* parameters,
                   int32_t overhang_strategy, int32_t cigar_capacity, int32_t* cigar_ops, int32_t* cigar_lengths,
-                  int32_t* cigar_counts, int32_t* alignment_offsets) {
+                  int32_t* cigar_counts, int32_t* alignment_offsets) try {
     if (num_pairs < 0) return fail(GATK_SW_ILLEGAL_ARGUMENT, "negative pair count");
     if (num_pairs == 0) return GATK_SW_OK;
     if (!references || !reference_lengths || !alternates || !alternate_lengths || !parameters || !cigar_ops || !cigar_lengths ||
@@ -567,6 +569,10 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
         alignment_offsets[k] = results[k].offset;
     }
     return rc;
+} catch (const std::bad_alloc&) {  // no C++ exception crosses the C boundary
+    return fail(GATK_SW_DEVICE_ERROR, "host memory exhausted");
+} catch (const std::exception& e) {
+    return fail(GATK_SW_DEVICE_ERROR, std::string("internal error: ") + e.what());
 }
 
 }  // extern "C"
