@@ -16,6 +16,16 @@
 // that the 64 lanes of a store write 128 consecutive bytes; a second kernel, one thread per pair, picks
 // the end cell and walks the matrix through the same index map.  The host reverses and consolidates the
 // few CIGAR elements.
+//
+// Two cell forms.  The plain one keeps a gap's score and its length in two registers and follows the
+// reference statement by statement (about 30 vector instructions per cell).  The packed one keeps them in one
+// 32-bit word, score * 2^(S+2) + priority * 2^S + length, so that "the better score, and on equal scores the
+// longer (older) gap" is one signed max, and the three-way choice diagonal > horizontal > vertical, which the
+// reference settles with >= tests in that order, is one max of three such words whose priority fields are
+// 2, 1 and 0: 12 vector instructions per cell, and the low 16 bits of the winning word are the back-track
+// entry.  A pair takes the packed form when its lengths fit S <= 14 bits and every score the matrix can
+// hold fits the 30 - S bits left (checked on the host from the weights and the lengths); any other pair
+// takes the plain form.  Both give the reference's integers.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -38,6 +48,7 @@ constexpr int kMaxRowsPerLane = 32;
 constexpr int kMaxRef = kWave * kMaxRowsPerLane;  // 2048
 constexpr int kHeadElems = 16;  // raw CIGAR elements of a pair that come back with the first copy
 constexpr int kNumRowChoices = 13;
+constexpr int kNumGroups = 2 * kNumRowChoices;  // launch groups: (rows per lane, cell form), the packed form the odd ones
 constexpr int kRowChoices[kNumRowChoices] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 24, 32};  // rows per lane a fill kernel exists for
 constexpr int kMaxAlt = 16000;
 constexpr size_t kStagedPoolBytes = 1 << 20;      // sequence pools from this size on go up one launch at a time
@@ -52,6 +63,7 @@ struct PairDesc {
     int64_t elem_off;              // int32 offset of its raw CIGAR element list (2 ints per element)
     int32_t n, m;                  // reference / alternate length
     int32_t elem_cap;
+    int32_t len_bits;              // S of the packed cell form this pair's matrix was filled in; 0: the plain form
 };
 
 struct PairResult {
@@ -169,6 +181,101 @@ __global__ void __launch_bounds__(kWave) sw_fill(const SwArgs A, const int first
     }
 }
 
+// The packed cell form (see the head of the file).  A word is score * 2^Q + priority * 2^S + length with
+// Q = S + 2; scores that carry no gap (cells, the first row and column) are score * 2^Q with the low bits zero.
+//   vertical gap    Wv = max(up + open_v, Wv + ext)      open_v = w_open * 2^Q + 1, ext = w_extend * 2^Q + 1
+//   horizontal gap  Wh = max(left + open_h, Wh + ext)    open_h = open_v + 2^S (priority 1)
+//   diagonal        sd = diag + (match ? w_match : w_mismatch) * 2^Q + 2 * 2^S
+//   cell            best = max(sd, Wh, Wv); value = best with the low Q bits cleared; back-track = low 16 bits
+// On equal scores the extended gap has the larger length field (>= 2 against 1), which is the reference's
+// "prev_gap > best_gap" (:283-298, :305-318); between the three candidates the priority field decides as the
+// reference's ">=" tests do (:320-331).  The "no gap yet" value is -1.5 * 2^30: below every word a real score
+// makes, and one extension (the only thing that happens to it before a real gap replaces it) cannot wrap it.
+// MATRIX_MIN_CUTOFF (:233) cannot be reached by a pair the host lets in here.
+template <int K>
+__global__ void __launch_bounds__(kWave) sw_fill_packed(const SwArgs A, const int first_pair) {
+    extern __shared__ uint8_t alt_lds[];  // [64 pad][alternate][64 pad]
+    const PairDesc P = A.pairs[A.order[first_pair + blockIdx.x]];
+    const int lane = threadIdx.x;
+    const int n = P.n, m = P.m;
+    const uint8_t* ref = A.pool + P.ref_off;
+    const uint8_t* alt = A.pool + P.alt_off;
+    for (int x = lane; x < m + 2 * kWave; x += kWave) {
+        const int j = x - kWave;
+        alt_lds[x] = (j >= 0 && j < m) ? alt[j] : 0;
+    }
+    __syncthreads();
+
+    const int S = P.len_bits, Q = S + 2;
+    const int unit = 1 << Q;
+    int w_eq = A.w_match * unit + (2 << S), w_ne = A.w_mismatch * unit + (2 << S);
+    asm volatile("" : "+v"(w_eq), "+v"(w_ne));  // two finished constants, not a select of weights with the shift behind it
+    const int ext = A.w_extend * unit + 1;
+    const int open_v = A.w_open * unit + 1, open_h = open_v + (1 << S);
+    const int none_v = -(3 << 29), none_h = none_v + (1 << S);
+    const int value_mask = ~(unit - 1);
+
+    const int row0 = lane * K + 1;
+    int a_base[K], left[K], wh[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        const int i = row0 + r;
+        a_base[r] = i <= n ? ref[i - 1] : 0x100;
+        left[r] = edge_score(A, i) * unit;
+        wh[r] = none_h;
+    }
+    int diag0 = edge_score(A, row0 - 1) * unit;
+    int out_sw = 0, out_wv = none_v;
+    int16_t* const bt = A.btrack + P.btrack_off;
+    int32_t* const last_col = A.edges + P.edge_off;
+    int32_t* const bottom = last_col + (n + 1);
+    const int steps = m + (n + K - 1) / K - 1;
+    const int last_row_lane = (n - 1) / K, last_row_r = (n - 1) % K;
+    for (int s = 0; s < steps; ++s) {
+        int up = shr1(out_sw), wv = shr1(out_wv);
+        const int j = s - lane + 1;
+        if (lane == 0) { up = edge_score(A, j) * unit; wv = none_v; }
+        if (j >= 1 && j <= m) {
+            const int b_base = alt_lds[kWave + j - 1];
+            const int up_in = up;
+            int16_t* const bt_step = bt + static_cast<int64_t>(s) * K * kWave + lane;
+            // everything that reads the previous column first (after it a row's old value is dead and the new one
+            // takes its register), then the chain down the rows
+            int sd[K];
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                sd[r] = (r == 0 ? diag0 : left[r - 1]) + (a_base[r] == b_base ? w_eq : w_ne);
+                wh[r] = max(left[r] + open_h, wh[r] + ext);
+            }
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                wv = max(up + open_v, wv + ext);
+                const int best = max(max(sd[r], wh[r]), wv);
+#ifndef SW_TIMING_WITHOUT_STORES
+                bt_step[r * kWave] = static_cast<int16_t>(best);
+#else
+                if (best == 0x12345678) bt_step[r * kWave] = 1;
+#endif
+                up = best & value_mask;
+                left[r] = up;
+            }
+            diag0 = up_in;
+            out_sw = up; out_wv = wv;
+            if (j == m) {
+#pragma unroll
+                for (int r = 0; r < K; ++r)
+                    if (row0 + r <= n) last_col[row0 + r] = left[r] >> Q;
+            }
+            if (lane == last_row_lane) {
+                int v = left[0];
+#pragma unroll
+                for (int r = 1; r < K; ++r) v = (r == last_row_r) ? left[r] : v;
+                bottom[j] = v >> Q;
+            }
+        }
+    }
+}
+
 // calculateCigar, :350-470, one thread per pair: the raw element list (last element first) and the offset.
 __global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A, const int first_pair, const int num) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,6 +294,11 @@ __global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A, const int fir
         if (count < kHeadElems) { heads[2 * count] = op; heads[2 * count + 1] = len; }
         ++count;
     };
+    // A packed entry is the low 16 bits of the winning word: length in the low len_bits bits, the priority (2 diagonal,
+    // 1 horizontal gap, 0 vertical gap) above them.  diag_code is what (entry & diag_mask) is for a diagonal step: the
+    // plain form's entries are the reference's btrack values themselves, 0 for a diagonal step.
+    const int len_bits = P.len_bits;
+    const int diag_mask = len_bits ? 3 << len_bits : -1, diag_code = len_bits ? 2 << len_bits : 0;
     int p1 = 0, p2 = 0, maxscore = INT_MIN, segment_length = 0;
     if (A.strategy == GATK_SW_INDEL) {
         p1 = refLength; p2 = altLength;
@@ -228,13 +340,19 @@ __global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A, const int fir
         const int span = min(kAhead, min(p1, p2));
         int ahead[kAhead];
 #pragma unroll
-        for (int q = 0; q < kAhead; ++q) ahead[q] = q < span ? bt[btrack_index(p1 - q, p2 - q, P.rows_per_lane)] : 0;
-        int matches = 0, btr = 0;
+        for (int q = 0; q < kAhead; ++q) ahead[q] = q < span ? bt[btrack_index(p1 - q, p2 - q, P.rows_per_lane)] : diag_code;
+        int matches = 0, raw = 0;
+        bool gap = false;
 #pragma unroll
         for (int q = 0; q < kAhead; ++q)
-            if (btr == 0 && q < span) {
-                if (ahead[q] == 0) matches = q + 1; else btr = ahead[q];
+            if (!gap && q < span) {
+                if ((ahead[q] & diag_mask) == diag_code) matches = q + 1; else { gap = true; raw = ahead[q]; }
             }
+        int btr = 0;  // the reference's btrack value of the gap: > 0 that many rows up, < 0 that many columns left
+        if (gap) {
+            if (len_bits == 0) btr = raw;
+            else { const int len = raw & ((1 << len_bits) - 1); btr = ((raw >> len_bits) & 3) == 1 ? -len : len; }
+        }
         if (matches > 0) {
             p1 -= matches; p2 -= matches;
             if (state == GATK_SW_OP_M) segment_length += matches;
@@ -266,6 +384,8 @@ __global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A, const int fir
 }
 
 thread_local std::string g_sw_error;
+// GATK_SW_PLAIN_CELLS=1 in the environment keeps every pair on the plain cell form (cross-checks, timing).
+const bool g_force_plain = [] { const char* e = std::getenv("GATK_SW_PLAIN_CELLS"); return e && e[0] == '1'; }();
 
 int fail(int code, const std::string& msg) {
     g_sw_error = msg;
@@ -337,8 +457,9 @@ hipError_t pinned_for(void** p, size_t* cap, size_t bytes) {
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 template <int K>
-hipError_t launch_fill(const SwArgs& A, int first, int count, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL((sw_fill<K>), dim3(count), dim3(kWave), lds, stream, A, first);
+hipError_t launch_fill(const SwArgs& A, bool packed, int first, int count, size_t lds, hipStream_t stream) {
+    if (packed) hipLaunchKernelGGL((sw_fill_packed<K>), dim3(count), dim3(kWave), lds, stream, A, first);
+    else hipLaunchKernelGGL((sw_fill<K>), dim3(count), dim3(kWave), lds, stream, A, first);
     return hipGetLastError();
 }
 
@@ -385,34 +506,50 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
         P.elem_off = static_cast<int64_t>(elem_ints); elem_ints += 2 * static_cast<size_t>(elem_stride);  // every pair the same stride: see the fetch
         max_m = std::max(max_m, m);
     }
-    // rows per lane: per pair, the smallest instantiation that holds its reference; one launch per value
+    // rows per lane: per pair, the smallest instantiation that holds its reference; cell form: packed where the
+    // pair's lengths and scores fit its fields (see sw_fill_packed).  One launch per (rows per lane, form) in use.
     std::vector<int32_t> order(num_pairs);
-    std::array<int, kNumRowChoices + 1> group_begin{};
+    std::array<int, kNumGroups + 1> group_begin{};
     {
-        std::array<int, kNumRowChoices> count{};
-        std::vector<uint8_t> choice(num_pairs);
+        const int64_t w_abs = std::max(std::abs(static_cast<int64_t>(parameters->w_match)), std::abs(static_cast<int64_t>(parameters->w_mismatch)));
+        const int64_t open_abs = std::abs(static_cast<int64_t>(parameters->w_open)), ext_abs = std::abs(static_cast<int64_t>(parameters->w_extend));
+        const bool gaps_cost = parameters->w_open <= 0 && parameters->w_extend <= 0;  // what the score bound below assumes
+        std::array<int, kNumGroups> count{};
+        std::vector<uint8_t> group(num_pairs);
         for (int k = 0; k < num_pairs; ++k) {
             PairDesc& P = pairs[k];
             const int need = (P.n + kWave - 1) / kWave;
             int c = 0;
             while (kRowChoices[c] < need) ++c;
             const int K = kRowChoices[c];
-            choice[k] = static_cast<uint8_t>(c);
-            ++count[c];
+            // Packed form: a gap length (at most the rows the wave computes, 64 K, or the alternate's length) must
+            // stay below 2^S - 1, and every score of the matrix below 2^(28 - S) in magnitude.  A cell is at most
+            // min(rows, m) diagonal steps of the larger weight above its edge, and at least one gap along its row
+            // below it: value(i, j) >= edge(i) + w_open + (j - 1) w_extend.
+            const int64_t rows = static_cast<int64_t>(kWave) * K, longest = std::max<int64_t>(rows, P.m);
+            int S = 4;
+            while ((int64_t{1} << S) < longest + 3) ++S;
+            const int64_t bound = w_abs * (std::min<int64_t>(rows, P.m) + 2) + 2 * open_abs + (rows + P.m + 2) * ext_abs;
+            const bool packed = !g_force_plain && gaps_cost && S <= 14 && bound < (int64_t{1} << (28 - S)) &&
+                                std::max(w_abs, std::max(open_abs, ext_abs)) < (int64_t{1} << (26 - S));
+            P.len_bits = packed ? S : 0;
+            const int g = 2 * c + (packed ? 1 : 0);
+            group[k] = static_cast<uint8_t>(g);
+            ++count[g];
             const size_t steps = static_cast<size_t>(P.m) + (P.n + K - 1) / K - 1;
             P.rows_per_lane = K;
             P.btrack_off = static_cast<int64_t>(bt_entries);
             bt_entries += steps * K * kWave;
         }
-        for (int c = 0; c < kNumRowChoices; ++c) group_begin[c + 1] = group_begin[c] + count[c];
-        std::array<int, kNumRowChoices> at{};
-        for (int k = 0; k < num_pairs; ++k) order[group_begin[choice[k]] + at[choice[k]]++] = k;
+        for (int g = 0; g < kNumGroups; ++g) group_begin[g + 1] = group_begin[g] + count[g];
+        std::array<int, kNumGroups> at{};
+        for (int k = 0; k < num_pairs; ++k) order[group_begin[group[k]] + at[group[k]]++] = k;
     }
     // the sequence pool in launch order (most rows per lane first), so that a launch's sequences are one range of it
-    std::array<size_t, kNumRowChoices + 1> group_pool{};  // group c's sequences: [group_pool[c + 1], group_pool[c])
-    for (int c = kNumRowChoices - 1; c >= 0; --c) {
-        group_pool[c + 1] = pool_bytes;
-        for (int x = group_begin[c]; x < group_begin[c + 1]; ++x) {
+    std::array<size_t, kNumGroups + 1> group_pool{};  // group g's sequences: [group_pool[g + 1], group_pool[g])
+    for (int g = kNumGroups - 1; g >= 0; --g) {
+        group_pool[g + 1] = pool_bytes;
+        for (int x = group_begin[g]; x < group_begin[g + 1]; ++x) {
             PairDesc& P = pairs[order[x]];
             P.ref_off = static_cast<int64_t>(pool_bytes); pool_bytes += align_up(P.n, 16);
             P.alt_off = static_cast<int64_t>(pool_bytes); pool_bytes += align_up(P.m, 16);
@@ -440,8 +577,8 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
     SW_TRY(pinned_for(&sc->up, &sc->up_cap, upload_bytes));
     uint8_t* host = static_cast<uint8_t*>(sc->up);
     const bool staged = pool_bytes >= kStagedPoolBytes;
-    auto pack = [&](int c) {
-        for (int x = group_begin[c]; x < group_begin[c + 1]; ++x) {
+    auto pack = [&](int g) {
+        for (int x = group_begin[g]; x < group_begin[g + 1]; ++x) {
             const int k = order[x];
             memcpy(host + o_pool + pairs[k].ref_off, references[k], pairs[k].n);
             memcpy(host + o_pool + pairs[k].alt_off, alternates[k], pairs[k].m);
@@ -450,7 +587,7 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
     memcpy(host + o_pairs, pairs.data(), pairs.size() * sizeof(PairDesc));
     memcpy(host + o_order, order.data(), order.size() * sizeof(int32_t));
     if (!staged)
-        for (int c = 0; c < kNumRowChoices; ++c) pack(c);
+        for (int g = 0; g < kNumGroups; ++g) pack(g);
     SW_TRY(hipMemcpyAsync(D, host, staged ? o_pool : upload_bytes, hipMemcpyHostToDevice, stream));
     SwArgs A{};
     A.pool = D + o_pool;
@@ -468,8 +605,8 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
     SW_TRY(hipEventRecord(sc->fork, stream));
     int launches = 0;
     bool side_used[kSideStreams] = {};
-    for (int c = kNumRowChoices - 1; c >= 0; --c) {  // most rows per lane first: those waves run longest
-        const int first = group_begin[c], count = group_begin[c + 1] - first;
+    for (int g = kNumGroups - 1; g >= 0; --g) {  // most rows per lane first: those waves run longest
+        const int first = group_begin[g], count = group_begin[g + 1] - first;
         if (count == 0) continue;
         hipStream_t stream = sc->main;  // the first launch stays on the main stream, the others fan out
         if (launches > 0) {
@@ -480,25 +617,26 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
         }
         ++launches;
         if (staged) {
-            pack(c);
-            SW_TRY(hipMemcpyAsync(D + o_pool + group_pool[c + 1], host + o_pool + group_pool[c + 1], group_pool[c] - group_pool[c + 1],
+            pack(g);
+            SW_TRY(hipMemcpyAsync(D + o_pool + group_pool[g + 1], host + o_pool + group_pool[g + 1], group_pool[g] - group_pool[g + 1],
                                   hipMemcpyHostToDevice, stream));
         }
+        const bool packed = (g & 1) != 0;
         hipError_t e = hipErrorInvalidValue;
-        switch (kRowChoices[c]) {
-            case 1: e = launch_fill<1>(A, first, count, lds, stream); break;
-            case 2: e = launch_fill<2>(A, first, count, lds, stream); break;
-            case 3: e = launch_fill<3>(A, first, count, lds, stream); break;
-            case 4: e = launch_fill<4>(A, first, count, lds, stream); break;
-            case 5: e = launch_fill<5>(A, first, count, lds, stream); break;
-            case 6: e = launch_fill<6>(A, first, count, lds, stream); break;
-            case 7: e = launch_fill<7>(A, first, count, lds, stream); break;
-            case 8: e = launch_fill<8>(A, first, count, lds, stream); break;
-            case 10: e = launch_fill<10>(A, first, count, lds, stream); break;
-            case 12: e = launch_fill<12>(A, first, count, lds, stream); break;
-            case 16: e = launch_fill<16>(A, first, count, lds, stream); break;
-            case 24: e = launch_fill<24>(A, first, count, lds, stream); break;
-            case 32: e = launch_fill<32>(A, first, count, lds, stream); break;
+        switch (kRowChoices[g / 2]) {
+            case 1: e = launch_fill<1>(A, packed, first, count, lds, stream); break;
+            case 2: e = launch_fill<2>(A, packed, first, count, lds, stream); break;
+            case 3: e = launch_fill<3>(A, packed, first, count, lds, stream); break;
+            case 4: e = launch_fill<4>(A, packed, first, count, lds, stream); break;
+            case 5: e = launch_fill<5>(A, packed, first, count, lds, stream); break;
+            case 6: e = launch_fill<6>(A, packed, first, count, lds, stream); break;
+            case 7: e = launch_fill<7>(A, packed, first, count, lds, stream); break;
+            case 8: e = launch_fill<8>(A, packed, first, count, lds, stream); break;
+            case 10: e = launch_fill<10>(A, packed, first, count, lds, stream); break;
+            case 12: e = launch_fill<12>(A, packed, first, count, lds, stream); break;
+            case 16: e = launch_fill<16>(A, packed, first, count, lds, stream); break;
+            case 24: e = launch_fill<24>(A, packed, first, count, lds, stream); break;
+            case 32: e = launch_fill<32>(A, packed, first, count, lds, stream); break;
         }
         SW_TRY(e);
     }

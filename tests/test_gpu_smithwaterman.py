@@ -137,3 +137,55 @@ def test_errors():
     with pytest.raises(sw.CigarTooLong):
         sw.align_batch([b"AAAAACCCCCGGGGG"], [b"AAAAAGGGGG"], cigar_capacity=2)
     assert sw.align_batch([], []) == []
+
+
+NEW_SW = (200, -150, -260, -11)  # the heaviest weights GATK ships: they overflow the packed cell's score field on long pairs
+
+
+def test_both_cell_forms_in_one_call(oracle):
+    """Short pairs take the packed cell form, pairs whose scores or lengths do not fit its fields the plain one."""
+    rng = np.random.default_rng(21)
+    refs, alts = [], []
+    for ref_len in (30, 250, 400, 640, 1000, 1500, 2040, 505, 509, 1019, 1021):
+        r, a = random_pairs(rng, 2, ref_len, 3)
+        refs += r
+        alts += a
+    refs.append(b"ACGT" * 40)
+    alts.append(b"ACGT" * 3000)  # an alternate far longer than any reference row count
+    for parameters in (NEW_SW, sw.ORIGINAL_DEFAULT):
+        for strategy in (sw.SOFTCLIP, sw.INDEL):
+            got = sw.align_batch(refs, alts, parameters, strategy, cigar_capacity=256)
+            for r, a, g in zip(refs, alts, got):
+                rc, c, o = oracle.sw_align(r, a, parameters, strategy)
+                assert rc == 0 and g == (c, o), (len(r), len(a), parameters, strategy)
+
+
+def test_weights_beyond_the_packed_fields(oracle):
+    rng = np.random.default_rng(22)
+    refs, alts = random_pairs(rng, 12, 200, 60)
+    heavy = (200000, -150000, -260000, -11000)
+    got = sw.align_batch(refs, alts, heavy, sw.SOFTCLIP)
+    for r, a, g in zip(refs, alts, got):
+        rc, c, o = oracle.sw_align(r, a, heavy, sw.SOFTCLIP)
+        assert rc == 0 and g == (c, o)
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+def test_ties_in_low_complexity_sequences(oracle, strategy):
+    """Repeats make equal scores everywhere: the order diagonal, horizontal gap, vertical gap and 'an older gap wins a
+    tie with a newly opened one' decide the CIGAR."""
+    rng = np.random.default_rng(23 + strategy)
+    refs, alts = [], []
+    for unit in ("A", "AC", "ACG", "AACC", "ACGTT"):
+        for n in (17, 64, 130, 333):
+            ref = (unit * (n // len(unit) + 1))[:n]
+            alt = mutate(rng, ref, 2, 3)
+            refs.append(ref.encode())
+            alts.append(alt.encode())
+            refs.append(alt.encode())
+            alts.append(ref.encode())
+    for parameters in (sw.ORIGINAL_DEFAULT, (1, -1, -1, -1), (2, -2, -2, 0), sw.STANDARD_NGS):
+        got = sw.align_batch(refs, alts, parameters, strategy, cigar_capacity=512)
+        for r, a, g in zip(refs, alts, got):
+            rc, c, o = oracle.sw_align(r, a, parameters, strategy)
+            assert rc == 0 and g == (c, o), (r, a, parameters)
