@@ -251,7 +251,10 @@ __global__ void __launch_bounds__(kWave) sw_fill_packed(const SwArgs A, const in
             for (int r = 0; r < K; ++r) {
                 wv = max(up + open_v, wv + ext);
                 const int best = max(max(sd[r], wh[r]), wv);
-#ifndef SW_TIMING_WITHOUT_STORES
+                // the two SW_TIMING_ builds store half the bytes or none (wrong alignments: for timing what the stores cost)
+#if defined(SW_TIMING_BYTE_STORES)
+                reinterpret_cast<int8_t*>(bt)[(static_cast<int64_t>(s) * K + r) * kWave + lane] = static_cast<int8_t>(best);
+#elif !defined(SW_TIMING_WITHOUT_STORES)
                 bt_step[r * kWave] = static_cast<int16_t>(best);
 #else
                 if (best == 0x12345678) bt_step[r * kWave] = 1;
@@ -336,6 +339,9 @@ __global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A, const int fir
     // kAhead cells of the diagonal are fetched together, the leading zeros among them are that many match
     // steps at once, the first non-zero one is a gap handled as in the reference's loop (:401-430).
     constexpr int kAhead = 8;
+    // every round moves at least one cell towards row 0 or column 0; the bound only keeps a damaged matrix from
+    // holding the wave forever
+    int rounds_left = refLength + altLength + 1;
     do {
         const int span = min(kAhead, min(p1, p2));
         int ahead[kAhead];
@@ -365,7 +371,7 @@ __global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A, const int fir
             if (new_state == state) segment_length += step_length;
             else { add(state, segment_length); segment_length = step_length; state = new_state; }
         }
-    } while (p1 > 0 && p2 > 0);
+    } while (p1 > 0 && p2 > 0 && --rounds_left > 0);
     int offset;
     if (A.strategy == GATK_SW_SOFTCLIP) {
         add(state, segment_length);
