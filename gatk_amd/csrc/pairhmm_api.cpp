@@ -46,6 +46,8 @@ hipError_t launch_marginalize_reads(const DeviceBatch& B, const int32_t* old_to_
 hipError_t launch_prepare(const DeviceBatch& B, bool expand_rows, bool stream, hipStream_t s);
 hipError_t launch_upload(const void* pinned_host, void* device, size_t bytes, hipStream_t s);
 hipError_t launch_download(void* device, void* pinned_host, size_t bytes, size_t clear_bytes, hipStream_t s);
+hipError_t launch_download_and_signal(void* device, void* pinned_host, size_t bytes, size_t clear_bytes, unsigned* pinned_flag,
+                                      unsigned seq, hipStream_t s);
 }  // namespace pairhmm_hip
 
 using namespace pairhmm_hip;
@@ -171,7 +173,9 @@ struct PinnedBuf {
             if (e != hipSuccess) return e;
         }
         size_t want = bytes + bytes / 2 + 4096;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        // coherent (fine-grained) whatever the process environment says about the default: a kernel's stores into
+        // the buffer are read by the host while the kernel is still running (download_and_signal)
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocCoherent);
         if (e == hipSuccess) cap = want;
         return e;
     }
@@ -319,6 +323,9 @@ struct gatk_pairhmm {
     int wave_slots = 3072;  // waves the device holds at once at three per SIMD
     size_t kernel_upload_bytes = size_t{1} << 20;  // uploads up to this size are copied by a kernel, not by the DMA engine
     size_t kernel_download_bytes = size_t{512} << 10;  // results of at most this many bytes are copied back by a kernel
+    size_t signal_download_bytes = size_t{64} << 10;   // ... and of at most this many by one block that then raises a flag the host polls
+    PinnedBuf done_flag;                               // that flag (one word of pinned host memory)
+    unsigned done_seq = 0;                             // value the next such download stores there
     int64_t per_group_factor = 32;  // calls with at least this many pairs per wave slot choose rows per lane per wave-group
     bool combine_calls = false;  // small compute_likelihoods calls of all threads on this device share device passes
     bool pipeline_ramp = true;  // the first two parts of a cut call are a quarter and a half of pipeline_pairs
@@ -1325,14 +1332,37 @@ int download_into(gatk_pairhmm* h, gatk_pairhmm_resident* R, double* const* outs
     const size_t down_bytes = (kCounterBytes + bytes + 255) & ~size_t{255};
     const bool by_kernel = down_bytes <= h->kernel_download_bytes && down_bytes <= h->stage_out.cap && down_bytes <= R->d_out.cap &&
                            static_cast<void*>(R->counters()) == R->d_out.p;
-    if (by_kernel) HIP_TRY(launch_download(R->d_out.p, h->stage_out.p, down_bytes, kCounterBytes, R->stream));
-    else HIP_TRY(hipMemcpyAsync(h->stage_out.p, R->d_out.p, kCounterBytes + bytes, hipMemcpyDeviceToHost, R->stream));
-    // the host waits for the copy only; the runtime's copy leaves the counters to a memset behind it
-    if (!R->ev_downloaded) HIP_TRY(hipEventCreateWithFlags(&R->ev_downloaded, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(R->ev_downloaded, R->stream));
-    if (!by_kernel) HIP_TRY(hipMemsetAsync(R->counters(), 0, kCounterBytes, R->stream));
-    R->counters_clear = true;
-    HIP_TRY(hipEventSynchronize(R->ev_downloaded));
+    // (not with pass timings pending: their events are read right after, and only a wait through the runtime makes them readable)
+    const bool by_signal = by_kernel && down_bytes <= h->signal_download_bytes && R->ev_pending.empty();
+    bool waited = false;
+    if (by_signal) {
+        if (!h->done_flag.p) {
+            HIP_TRY(h->done_flag.ensure(64));
+            *static_cast<volatile unsigned*>(h->done_flag.p) = 0;
+        }
+        const unsigned seq = ++h->done_seq ? h->done_seq : ++h->done_seq;  // never 0, the flag's initial value
+        unsigned* const flag = static_cast<unsigned*>(h->done_flag.p);
+        HIP_TRY(launch_download_and_signal(R->d_out.p, h->stage_out.p, down_bytes, kCounterBytes, flag, seq, R->stream));
+        R->counters_clear = true;
+        // A region-sized pass is over in tens of microseconds: poll for them, then leave the rest to the runtime
+        // (which also reports a failed launch; the flag alone would never come).
+        const double t_poll = now_ms();
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { waited = true; break; }
+            __builtin_ia32_pause();
+            if ((spins & 1023u) == 1023u && now_ms() - t_poll > 2.0) break;
+        }
+        if (!waited) HIP_TRY(hipStreamSynchronize(R->stream));
+    } else {
+        if (by_kernel) HIP_TRY(launch_download(R->d_out.p, h->stage_out.p, down_bytes, kCounterBytes, R->stream));
+        else HIP_TRY(hipMemcpyAsync(h->stage_out.p, R->d_out.p, kCounterBytes + bytes, hipMemcpyDeviceToHost, R->stream));
+        // the host waits for the copy only; the runtime's copy leaves the counters to a memset behind it
+        if (!R->ev_downloaded) HIP_TRY(hipEventCreateWithFlags(&R->ev_downloaded, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(R->ev_downloaded, R->stream));
+        if (!by_kernel) HIP_TRY(hipMemsetAsync(R->counters(), 0, kCounterBytes, R->stream));
+        R->counters_clear = true;
+        HIP_TRY(hipEventSynchronize(R->ev_downloaded));
+    }
     if (int rc = digest_counters(h, R, static_cast<const int32_t*>(h->stage_out.p))) return rc;
     const double* src = reinterpret_cast<const double*>(static_cast<const uint8_t*>(h->stage_out.p) + kCounterBytes);
     for (int k = 0; k < R->num_regions; ++k) {
@@ -2050,6 +2080,7 @@ int gatk_pairhmm_close(gatk_pairhmm* h) try {
     if (h->stage_in_copied) { (void)hipEventSynchronize(h->stage_in_copied); (void)hipEventDestroy(h->stage_in_copied); }
     h->stage_in.release();
     h->stage_out.release();
+    h->done_flag.release();
     if (h->d_err) (void)hipFree(h->d_err);
     if (h->d_mm) (void)hipFree(h->d_mm);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -2089,6 +2120,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) try
     else if (n == "combine_calls") h->combine_calls = value != 0;
     else if (n == "per_group_factor") h->per_group_factor = std::max<int64_t>(1, static_cast<int64_t>(value));
     else if (n == "kernel_download_bytes") h->kernel_download_bytes = static_cast<size_t>(std::max(0.0, value));
+    else if (n == "signal_download_bytes") h->signal_download_bytes = static_cast<size_t>(std::max(0.0, value));
     else if (n == "kernel_upload_bytes") h->kernel_upload_bytes = static_cast<size_t>(std::max(0.0, value));
     else if (n == "wave_slots") h->wave_slots = std::max(64, static_cast<int>(value));
     else if (n == "stream_lds_floor") h->stream_lds_floor = std::max(0, static_cast<int>(value));

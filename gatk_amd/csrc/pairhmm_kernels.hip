@@ -1452,6 +1452,29 @@ __global__ void __launch_bounds__(256) download_to_host(uint4* src, uint4* __res
     }
 }
 
+// The same in one block that then announces itself: every thread makes its stores visible to the host, the block
+// meets, and one thread stores `seq` into a word of pinned host memory the caller is polling.  The host sees the
+// result a fraction of a microsecond after the last store instead of after the end-of-kernel signal has made its
+// way through the runtime.
+__global__ void __launch_bounds__(1024) download_and_signal(uint4* src, uint4* __restrict__ dst, const int n16, const int clear16,
+                                                            unsigned* flag, const unsigned seq) {
+    for (int k = threadIdx.x; k < n16; k += blockDim.x) {
+        dst[k] = src[k];
+        if (k < clear16) src[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_download_and_signal(void* device, void* pinned_host, size_t bytes, size_t clear_bytes, unsigned* pinned_flag,
+                                      unsigned seq, hipStream_t s) {
+    const int n16 = static_cast<int>((bytes + 15) / 16);
+    hipLaunchKernelGGL(download_and_signal, dim3(1), dim3(n16 <= 256 ? 256 : n16 <= 512 ? 512 : 1024), 0, s, static_cast<uint4*>(device),
+                       static_cast<uint4*>(pinned_host), n16, static_cast<int>(clear_bytes / 16), pinned_flag, seq);
+    return hipGetLastError();
+}
+
 hipError_t launch_download(void* device, void* pinned_host, size_t bytes, size_t clear_bytes, hipStream_t s) {
     const int n16 = static_cast<int>((bytes + 15) / 16);
     if (n16 <= 0) return hipSuccess;
