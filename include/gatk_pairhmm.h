@@ -211,7 +211,11 @@ int gatk_pairhmm_device_count(int32_t* count);
  *   "kernel_download_bytes" default 524288: results of at most that many bytes (counters included) come back through
  *                         the same kind of kernel, device to pinned host memory: the runtime's copy starts 5-6 us
  *                         after the kernel in front of it.
- *   "wave_slots"          waves the planner assumes the device holds at once, default 12 per CU (occupancy
+ *   "signal_download_bytes" default 65536: results of at most that many bytes come back through one block that,
+ *                         after its stores, raises a flag in pinned host memory which the calling thread polls (for
+ *                         2 ms at most, then it waits through the runtime): the caller sees a region-sized result
+ *                         about 5 us earlier than through an event.  0 turns it off.
+ *   "wave_slots"         waves the planner assumes the device holds at once, default 12 per CU (occupancy
  *                         experiments).
  *   "stream_lds_floor"    least bytes of LDS a wave of the fp32 stream pass asks for; a larger value lowers the
  *                         number of waves a CU holds (occupancy experiments).
