@@ -6,7 +6,10 @@
 // one big call against region-at-a-time calls and against calls of a few dozen regions on a default handle,
 // host-pointer calls against the resident path, a multi-device handle (three engines on GPU 0) against one engine
 // for calls of many regions, few regions and one region cut by read ranges, and eight threads whose one-region
-// calls are combined into shared passes.
+// calls are combined into shared passes.  Last, Smith-Waterman calls of random sizes (a handful of pairs, thousands of
+// them with a sequence pool large enough to go up launch by launch, weights on both sides of the packed cell form's
+// limits, alignments with more elements than come back with the first copy): an alignment's elements must add up to its
+// sequences.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -15,6 +18,7 @@
 #include <vector>
 
 #include "../include/gatk_pairhmm.h"
+#include "../include/gatk_smithwaterman.h"
 
 namespace {
 
@@ -263,6 +267,49 @@ int main(int argc, char** argv) {
         if (std::fabs(one - got[0]) > 1e-3) { std::printf("pair call differs from the queue: %g vs %g\n", one, got[0]); return 1; }
         break;
     }
+    // Smith-Waterman
+    for (int round = 0; round < 6; ++round) {
+        const int n_pairs = round == 5 ? 3000 : g.range(1, 40);
+        std::vector<std::vector<uint8_t>> refs(n_pairs), alts(n_pairs);
+        std::vector<const uint8_t*> rp(n_pairs), ap(n_pairs);
+        std::vector<int32_t> rl(n_pairs), al(n_pairs);
+        for (int k = 0; k < n_pairs; ++k) {
+            const int n = round == 5 ? g.range(200, 500) : g.range(1, g.range(0, 9) == 0 ? 2048 : 600);
+            for (int i = 0; i < n; ++i) refs[k].push_back("ACGT"[g.range(0, 3)]);
+            alts[k] = refs[k];
+            const int indels = round == 4 ? 24 : g.range(0, 3);  // round 4: more elements than the first copy brings back
+            for (int e = 0; e < indels && alts[k].size() > 40; ++e) {
+                const size_t at = static_cast<size_t>(g.range(1, static_cast<int>(alts[k].size()) - 8));
+                if (g.range(0, 1)) alts[k].erase(alts[k].begin() + at, alts[k].begin() + at + static_cast<size_t>(g.range(1, 6)));
+                else alts[k].insert(alts[k].begin() + at, static_cast<size_t>(g.range(1, 6)), static_cast<uint8_t>('T'));
+            }
+            for (int e = g.range(0, 4); e > 0; --e) alts[k][static_cast<size_t>(g.range(0, static_cast<int>(alts[k].size()) - 1))] = "ACGT"[g.range(0, 3)];
+            rp[k] = refs[k].data(); ap[k] = alts[k].data();
+            rl[k] = static_cast<int32_t>(refs[k].size()); al[k] = static_cast<int32_t>(alts[k].size());
+        }
+        const gatk_sw_parameters sets[4] = {{3, -1, -4, -3}, {25, -50, -110, -6}, {200, -150, -260, -11}, {200000, -150000, -260000, -11000}};
+        const gatk_sw_parameters par = sets[g.range(0, 3)];
+        const int strategy = g.range(0, 3);
+        const int cap = 128;
+        std::vector<int32_t> ops(static_cast<size_t>(n_pairs) * cap), lens(ops.size()), counts(n_pairs), offs(n_pairs);
+        const int rc = gatk_sw_align(0, n_pairs, rp.data(), rl.data(), ap.data(), al.data(), &par, strategy, cap, ops.data(), lens.data(), counts.data(), offs.data());
+        if (rc != GATK_SW_OK) { std::printf("gatk_sw_align: %s\nFAILED\n", gatk_sw_last_error()); return 1; }
+        for (int k = 0; k < n_pairs; ++k) {
+            int64_t on_alt = 0, on_ref = 0;
+            for (int e = 0; e < counts[k]; ++e) {
+                const int op = ops[static_cast<size_t>(k) * cap + e], len = lens[static_cast<size_t>(k) * cap + e];
+                if (op == GATK_SW_OP_M) { on_alt += len; on_ref += len; }
+                else if (op == GATK_SW_OP_I || op == GATK_SW_OP_S) on_alt += len;
+                else on_ref += len;
+            }
+            // the elements account for the whole alternate; the reference span fits the reference from the offset on
+            // (IGNORE folds the unaligned head of the alternate into its first element, whatever that is, and its
+            // offset may be negative: there only the presence of an alignment is checked)
+            const bool ok = strategy == GATK_SW_IGNORE ? counts[k] >= 1 : (on_alt == al[k] && offs[k] >= 0 && offs[k] + on_ref <= rl[k]);
+            if (!ok) { std::printf("Smith-Waterman pair %d of round %d: elements cover %lld alternate / %lld reference bases of %d / %d, offset %d\nFAILED\n", k, round, static_cast<long long>(on_alt), static_cast<long long>(on_ref), al[k], rl[k], offs[k]); return 1; }
+        }
+    }
+
     CHECK(gatk_pairhmm_close(h));
     CHECK(gatk_pairhmm_close(h2));
     CHECK(gatk_pairhmm_close(h3));
