@@ -165,7 +165,9 @@ struct DevBuf {
 struct PinnedBuf {
     void* p = nullptr;
     size_t cap = 0;
-    hipError_t ensure(size_t bytes) {
+    // coherent: fine-grained whatever the process environment says about the default, for memory the host reads
+    // while the kernel that writes it is still running (download_and_signal)
+    hipError_t ensure(size_t bytes, bool coherent = false) {
         if (bytes <= cap) return hipSuccess;
         if (p) {
             hipError_t e = hipHostFree(p);
@@ -173,9 +175,7 @@ struct PinnedBuf {
             if (e != hipSuccess) return e;
         }
         size_t want = bytes + bytes / 2 + 4096;
-        // coherent (fine-grained) whatever the process environment says about the default: a kernel's stores into
-        // the buffer are read by the host while the kernel is still running (download_and_signal)
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocCoherent);
+        hipError_t e = hipHostMalloc(&p, want, coherent ? hipHostMallocCoherent : hipHostMallocDefault);
         if (e == hipSuccess) cap = want;
         return e;
     }
@@ -325,6 +325,7 @@ struct gatk_pairhmm {
     size_t kernel_download_bytes = size_t{512} << 10;  // results of at most this many bytes are copied back by a kernel
     size_t signal_download_bytes = size_t{64} << 10;   // ... and of at most this many by one block that then raises a flag the host polls
     PinnedBuf done_flag;                               // that flag (one word of pinned host memory)
+    PinnedBuf signal_out;                              // and where such a result lands (coherent pinned memory)
     unsigned done_seq = 0;                             // value the next such download stores there
     int64_t per_group_factor = 32;  // calls with at least this many pairs per wave slot choose rows per lane per wave-group
     bool combine_calls = false;  // small compute_likelihoods calls of all threads on this device share device passes
@@ -1335,14 +1336,17 @@ int download_into(gatk_pairhmm* h, gatk_pairhmm_resident* R, double* const* outs
     // (not with pass timings pending: their events are read right after, and only a wait through the runtime makes them readable)
     const bool by_signal = by_kernel && down_bytes <= h->signal_download_bytes && R->ev_pending.empty();
     bool waited = false;
+    const uint8_t* landed = static_cast<const uint8_t*>(h->stage_out.p);
     if (by_signal) {
         if (!h->done_flag.p) {
-            HIP_TRY(h->done_flag.ensure(64));
+            HIP_TRY(h->done_flag.ensure(64, true));
             *static_cast<volatile unsigned*>(h->done_flag.p) = 0;
         }
+        HIP_TRY(h->signal_out.ensure(down_bytes, true));
+        landed = static_cast<const uint8_t*>(h->signal_out.p);
         const unsigned seq = ++h->done_seq ? h->done_seq : ++h->done_seq;  // never 0, the flag's initial value
         unsigned* const flag = static_cast<unsigned*>(h->done_flag.p);
-        HIP_TRY(launch_download_and_signal(R->d_out.p, h->stage_out.p, down_bytes, kCounterBytes, flag, seq, R->stream));
+        HIP_TRY(launch_download_and_signal(R->d_out.p, h->signal_out.p, down_bytes, kCounterBytes, flag, seq, R->stream));
         R->counters_clear = true;
         // A region-sized pass is over in tens of microseconds: poll for them, then leave the rest to the runtime
         // (which also reports a failed launch; the flag alone would never come).
@@ -1363,8 +1367,8 @@ int download_into(gatk_pairhmm* h, gatk_pairhmm_resident* R, double* const* outs
         R->counters_clear = true;
         HIP_TRY(hipEventSynchronize(R->ev_downloaded));
     }
-    if (int rc = digest_counters(h, R, static_cast<const int32_t*>(h->stage_out.p))) return rc;
-    const double* src = reinterpret_cast<const double*>(static_cast<const uint8_t*>(h->stage_out.p) + kCounterBytes);
+    if (int rc = digest_counters(h, R, reinterpret_cast<const int32_t*>(landed))) return rc;
+    const double* src = reinterpret_cast<const double*>(landed + kCounterBytes);
     for (int k = 0; k < R->num_regions; ++k) {
         const int64_t n = R->region_out_off[k + 1] - R->region_out_off[k];
         if (n > 0) memcpy(outs[k], src + R->region_out_off[k], static_cast<size_t>(n) * sizeof(double));
@@ -2081,6 +2085,7 @@ int gatk_pairhmm_close(gatk_pairhmm* h) try {
     h->stage_in.release();
     h->stage_out.release();
     h->done_flag.release();
+    h->signal_out.release();
     if (h->d_err) (void)hipFree(h->d_err);
     if (h->d_mm) (void)hipFree(h->d_mm);
     if (h->stream) (void)hipStreamDestroy(h->stream);
