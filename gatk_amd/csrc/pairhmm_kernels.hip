@@ -121,9 +121,45 @@ constexpr int lut_table_bytes(int k, int mode) { return is_lut(mode) ? lut_row_p
 __device__ __forceinline__ int lut_index(const int r, const int c, const int codes, const int lane) {
     return (((r / kLutRowsPerRead) * codes + c) * kWave + lane) * kLutRowsPerRead + (r % kLutRowsPerRead);
 }
-// the emission terms of the lane's K rows against the base code whose table offset is code_off
-template <typename T, int K, int CODES>
+// the emission terms of the lane's K rows against the base code whose table offset is code_off.
+// AHEAD: the read is one the caller issues a block of steps before it uses the terms.  The compiler otherwise sinks
+// such a read to its first use, one loop iteration later, and the wave then waits out the LDS latency there: nothing
+// to a SIMD with three waves, a quarter of the step time to a wave that has its SIMD to itself.  A volatile read
+// stays where it is written.
+// ROWS table entries of one lane from p (a pointer into LDS), read where the statement stands (volatile: see lut_emit;
+// the LDS address space is spelled out because address-space inference leaves volatile accesses as flat ones)
+template <int ROWS>
+__device__ __forceinline__ float4 lut_read_in_place(const unsigned char* p) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef float f3 __attribute__((ext_vector_type(3)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+#define LDS_VOLATILE(type) (const volatile __attribute__((address_space(3))) type*)
+    if constexpr (ROWS >= 4) { const f4 w = *(LDS_VOLATILE(f4) p); return make_float4(w.x, w.y, w.z, w.w); }
+    else if constexpr (ROWS == 3) { const f3 w = *(LDS_VOLATILE(f3) p); return make_float4(w.x, w.y, w.z, 0.0f); }
+    else if constexpr (ROWS == 2) { const f2 w = *(LDS_VOLATILE(f2) p); return make_float4(w.x, w.y, 0.0f, 0.0f); }
+    else { return make_float4(*(LDS_VOLATILE(float) p), 0.0f, 0.0f, 0.0f); }
+#undef LDS_VOLATILE
+}
+
+template <typename T, int K, int CODES, bool AHEAD = false>
 __device__ __forceinline__ void lut_emit(const unsigned char* tbl_lane, const unsigned code_off, T (&prior)[K]) {
+#ifndef PAIRHMM_LUT_PAIRS
+    if constexpr (AHEAD && K <= 8) {
+        const float4 a = lut_read_in_place<(K < 4 ? K : 4)>(tbl_lane + code_off);
+        prior[0] = a.x;
+        if constexpr (K > 1) prior[1] = a.y;
+        if constexpr (K > 2) prior[2] = a.z;
+        if constexpr (K > 3) prior[3] = a.w;
+        if constexpr (K > 4) {
+            const float4 b = lut_read_in_place<K - 4>(tbl_lane + code_off + CODES * kLutCodeStride);
+            prior[4] = b.x;
+            if constexpr (K > 5) prior[5] = b.y;
+            if constexpr (K > 6) prior[6] = b.z;
+            if constexpr (K > 7) prior[7] = b.w;
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int g = 0; g < lut_row_pairs(K); ++g) {
         const unsigned char* p = tbl_lane + code_off + g * CODES * kLutCodeStride;
@@ -545,6 +581,8 @@ __device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_id
         const uint16_t* hp = reinterpret_cast<const uint16_t*>(hap_img) + (kHapFrontPad - ld.seg_lane);
         const unsigned char* tbl_lane = slice + lane * 4 * kLutRowsPerRead;
         auto emit = [&](const unsigned code_off, T (&prior)[K]) { lut_emit<T, K, kCodes>(tbl_lane, code_off, prior); };
+        // reads issued a block ahead of their use; pinned in place where the wave is likely alone on its SIMD
+        auto emit_ahead = [&](const unsigned code_off, T (&prior)[K]) { lut_emit<T, K, kCodes, (K <= 6)>(tbl_lane, code_off, prior); };
         auto masked_step = [&](const int step) {
             const T Sin = shr1(w.Sout);
             const T Iin = shr1(w.Iout);
@@ -561,29 +599,29 @@ __device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_id
             if constexpr (K <= 6) {
                 if ((s & 1) && s < end) { masked_step(s); ++s; }
                 if (s + 4 <= end) {
-                    T mc[4][K];
+                    // two sets of emission terms take turns (no copy from "next" to "current" at the end of a block,
+                    // which would wait for the reads it has just issued)
+                    T ma[4][K], mb[4][K];
                     unsigned mn[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) emit(hp[s + u], mc[u]);
+                    for (int u = 0; u < 4; ++u) emit_ahead(hp[s + u], ma[u]);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) mn[u] = hp[s + 4 + u];
-                    for (; s + 4 <= end; s += 4) {
-                        T mx[4][K];
+                    auto masked_block = [&](T (&cur)[4][K], T (&nxt)[4][K]) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) emit(mn[u], mx[u]);
+                        for (int u = 0; u < 4; ++u) emit_ahead(mn[u], nxt[u]);
 #pragma unroll
                         for (int u = 0; u < 4; ++u) mn[u] = hp[s + 8 + u];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const T Sin = shr1(w.Sout);
                             const T Iin = shr1(w.Iout);
-                            if (static_cast<unsigned>(s + u - ld.seg_lane) < static_cast<unsigned>(H)) col(u, mc[u], Sin, Iin);
+                            if (static_cast<unsigned>(s + u - ld.seg_lane) < static_cast<unsigned>(H)) col(u, cur[u], Sin, Iin);
                         }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                            for (int r = 0; r < K; ++r) mc[u][r] = mx[u][r];
-                    }
+                        s += 4;
+                    };
+                    while (s + 8 <= end) { masked_block(ma, mb); masked_block(mb, ma); }
+                    if (s + 4 <= end) masked_block(ma, mb);
                 }
             }
             for (; s < end; ++s) masked_step(s);
@@ -597,25 +635,46 @@ __device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_id
             T pc[4][K];
             unsigned yn[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) emit(hp[s + u], pc[u]);
+            for (int u = 0; u < 4; ++u) emit_ahead(hp[s + u], pc[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) yn[u] = hp[s + 4 + u];
-            for (; s + 4 <= H; s += 4) {
-                T pn[4][K];
+            if constexpr (K <= 6) {
+                // a wave that is likely alone on its SIMD: the two sets of terms take turns, so that no block ends
+                // with a copy that waits for the reads it has just issued
+                T pd[4][K];
+                auto steady_block = [&](T (&cur)[4][K], T (&nxt)[4][K]) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) emit(yn[u], pn[u]);
+                    for (int u = 0; u < 4; ++u) emit_ahead(yn[u], nxt[u]);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) yn[u] = hp[s + 8 + u];  // past H: lands in the zeroed tail pad
+                    for (int u = 0; u < 4; ++u) yn[u] = hp[s + 8 + u];  // past H: lands in the zeroed tail pad
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const T Sin = shr1(w.Sout);
-                    const T Iin = shr1(w.Iout);
-                    col(u, pc[u], Sin, Iin);
+                    for (int u = 0; u < 4; ++u) {
+                        const T Sin = shr1(w.Sout);
+                        const T Iin = shr1(w.Iout);
+                        col(u, cur[u], Sin, Iin);
+                    }
+                    s += 4;
+                };
+                while (s + 8 <= H) { steady_block(pc, pd); steady_block(pd, pc); }
+                if (s + 4 <= H) steady_block(pc, pd);
+            } else {
+                for (; s + 4 <= H; s += 4) {
+                    T pn[4][K];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) emit_ahead(yn[u], pn[u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) yn[u] = hp[s + 8 + u];  // past H: lands in the zeroed tail pad
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const T Sin = shr1(w.Sout);
+                        const T Iin = shr1(w.Iout);
+                        col(u, pc[u], Sin, Iin);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int r = 0; r < K; ++r) pc[u][r] = pn[u][r];
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int r = 0; r < K; ++r) pc[u][r] = pn[u][r];
             }
         }
         PHASE_END(3);
