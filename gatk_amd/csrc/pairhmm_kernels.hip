@@ -44,16 +44,25 @@ namespace pairhmm_hip {
 // 5 termination, 6 tasks.
 #ifdef PAIRHMM_PHASE_CLOCKS
 __device__ unsigned long long g_phase_clocks[8];
-#define PHASE_BEGIN() long long phase_t0 = clock64()
-#define PHASE_END(n)                                                                         \
-    do {                                                                                     \
-        const long long phase_t1 = clock64();                                                \
-        if (lane == 0) atomicAdd(&g_phase_clocks[n], (unsigned long long)(phase_t1 - phase_t0)); \
-        phase_t0 = phase_t1;                                                                 \
+// The shares are kept in registers and added to the counters once, when the work item is over: an atomic in the
+// middle of the item would stand in front of every later global load of the wave (they return in order).
+#define PHASE_BEGIN() long long phase_t0 = clock64(); long long phase_acc[6] = {0, 0, 0, 0, 0, 0}
+#define PHASE_END(n)                                  \
+    do {                                              \
+        const long long phase_t1 = clock64();         \
+        phase_acc[n] += phase_t1 - phase_t0;          \
+        phase_t0 = phase_t1;                          \
+    } while (0)
+#define PHASE_FLUSH()                                                                              \
+    do {                                                                                           \
+        if (lane == 0)                                                                             \
+            for (int n_ = 0; n_ < 6; ++n_)                                                         \
+                if (phase_acc[n_] != 0) atomicAdd(&g_phase_clocks[n_], (unsigned long long)phase_acc[n_]); \
     } while (0)
 #else
 #define PHASE_BEGIN() do {} while (0)
 #define PHASE_END(n) do {} while (0)
+#define PHASE_FLUSH() do {} while (0)
 #endif
 
 namespace {
@@ -357,6 +366,91 @@ __device__ __forceinline__ RowConst make_row_const(const DeviceBatch& B, const i
     return c;
 }
 
+// The RowConst entries of a lane's K rows (entry of row r: first_row + r, kept inside 0 .. R + 1), for the kernel that
+// works them out itself.  The same arithmetic as make_row_const, entry by entry, laid out for a wave that is alone on
+// its SIMD: all quality bytes of all rows are fetched first, then all table entries, then the arithmetic, and what kind
+// of row an entry is (pad row, read row, last row, sum row) is settled by selects.  Row by row with a branch per kind,
+// the wave made some twenty dependent trips to memory, which was most of its set-up time.  Indices of rows that have no
+// byte of their own are held inside the read, so every load is valid and its result is dropped by the selects.
+template <int K>
+__device__ __forceinline__ void row_consts_of_lane(const DeviceBatch& B, const int read, const int ro, const int R, const int first_row,
+                                                   float4 (&c0)[K], float4 (&c1)[K], int& bad) {
+    int i_of[K], ia[K], ib[K];
+    const int last_byte = R > 0 ? R - 1 : 0;
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        int i = first_row + r;
+        i = i < 0 ? 0 : (i > R + 1 ? R + 1 : i);
+        i_of[r] = i;
+        const int a = i - 1 < 0 ? 0 : (i - 1 > last_byte ? last_byte : i - 1);
+        const int b = i > last_byte ? last_byte : i;
+        ia[r] = ro + a;  // byte of row i
+        ib[r] = ro + b;  // byte of row i + 1
+    }
+    unsigned x[K], qual[K], ins[K], del[K], gcp[K], ins_n[K], del_n[K], gcp_n[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) { x[r] = B.read_bases[ia[r]]; qual[r] = B.read_quals[ia[r]]; }
+    if (B.ins_gop) {
+#pragma unroll
+        for (int r = 0; r < K; ++r) { ins[r] = B.ins_gop[ia[r]]; ins_n[r] = B.ins_gop[ib[r]]; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < K; ++r) ins[r] = ins_n[r] = static_cast<unsigned>(kDefaultIndelQual);
+    }
+    if (B.del_gop) {
+#pragma unroll
+        for (int r = 0; r < K; ++r) { del[r] = B.del_gop[ia[r]]; del_n[r] = B.del_gop[ib[r]]; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < K; ++r) del[r] = del_n[r] = static_cast<unsigned>(kDefaultIndelQual);
+    }
+    if (B.gcp) {
+#pragma unroll
+        for (int r = 0; r < K; ++r) { gcp[r] = B.gcp[ia[r]]; gcp_n[r] = B.gcp[ib[r]]; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < K; ++r) gcp[r] = gcp_n[r] = static_cast<unsigned>(kDefaultGcp);
+    }
+    const unsigned mapq = (B.read_mapq && read >= 0) ? B.read_mapq[read] : 255u;
+    double e[K], t0[K], t2[K], t4[K], t5[K], eg[K], t0n[K], t2n[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        const bool real = i_of[r] >= 1 && i_of[r] <= R;
+        if (real && ((ins[r] | del[r] | gcp[r]) & 0x80u)) bad |= 1;
+        unsigned q = qual[r] < mapq ? qual[r] : mapq;  // what the PairHMM is handed: after the mapping-quality cap
+        if (B.squash_base_quals && q < kBaseQualityScoreThreshold) q = kMinUsableQScore;
+        if (real && q == 255) bad |= 2;
+        e[r] = B.err_prob[q];
+        t0[r] = B.match_to_match[(ins[r] & 127u) * 128u + (del[r] & 127u)];
+        t2[r] = B.err_prob[ins[r] & 127u];
+        t4[r] = B.err_prob[del[r] & 127u];
+        t5[r] = B.err_prob[gcp[r]];
+        eg[r] = B.err_prob[gcp_n[r]];
+        t0n[r] = B.match_to_match[(ins_n[r] & 127u) * 128u + (del_n[r] & 127u)];
+        t2n[r] = B.err_prob[ins_n[r] & 127u];
+    }
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        const int i = i_of[r];
+        const bool real = i >= 1 && i <= R, has_next = i < R, last = i == R, sum_row = i > R;
+        const double p = 1.0 - e[r];
+        const double q = (x[r] == 'N') ? p : e[r] / B.mismatch_divisor;  // a read 'N' matches every base
+        const double m2 = real ? t2[r] : 0.0, m4 = real ? t4[r] : 1.0;    // a pad row hands its deletion mass down unweighted
+        const double t1n = 1.0 - eg[r];
+        const float c_f = static_cast<float>(m2 * eg[r] / t2n[r]);
+        const float c_i = static_cast<float>(m2 * t1n / t0n[r]);
+        const float c_e = static_cast<float>(m4 * t1n / t0n[r]);
+        c0[r].x = real ? static_cast<float>(p * t0[r]) : (sum_row ? 1.0f : 0.0f);
+        c0[r].y = real ? static_cast<float>(q * t0[r]) : (sum_row ? 1.0f : 0.0f);
+        c0[r].z = real ? static_cast<float>(t5[r]) : 1.0f;
+        c0[r].w = (has_next && i >= 1) ? c_f : 0.0f;
+        c1[r].x = has_next ? (i >= 1 ? c_i : 0.0f) : (last ? static_cast<float>(m2) : 0.0f);  // last row: Sn = M + F * t2 = M + I
+        c1[r].y = has_next ? c_e : 0.0f;
+        c1[r].z = __uint_as_float(real ? x[r] : kNoBase);
+        c1[r].w = 0.0f;
+    }
+}
+
 template <typename T, int K, int MODE>
 __device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_idx, unsigned char* slice,
                                          const int lane, const bool queue_underflow) {
@@ -459,15 +553,7 @@ __device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_id
             // a region-sized call: no expansion pass ran, the same entries are worked out here (and the
             // quality checks with them)
             int bad = 0;
-#pragma unroll
-            for (int r = 0; r < K; ++r) {
-                int e = ld.first_row + r;
-                e = e < 0 ? 0 : (e > R + 1 ? R + 1 : e);
-                RowConst c{0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, kNoBase, 0u};
-                if (ld.read_idx >= 0) c = make_row_const(B, ld.read_idx, ro, R, e, bad);
-                c0[r] = make_float4(c.p_match, c.p_mismatch, c.t5, c.c_f);
-                c1[r] = make_float4(c.c_i, c.c_e, __uint_as_float(c.base), 0.0f);
-            }
+            row_consts_of_lane<K>(B, ld.read_idx, ro, R, ld.first_row, c0, c1, bad);
             if (bad) report_input_error(B, bad, ld.read_idx);
         }
 #pragma unroll
@@ -741,6 +827,7 @@ __device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_id
         }
     }
     PHASE_END(5);
+    PHASE_FLUSH();
 #ifdef PAIRHMM_PHASE_CLOCKS
     if (lane == 0) atomicAdd(&g_phase_clocks[6], 1ull);
 #endif
@@ -961,6 +1048,7 @@ __device__ __forceinline__ void run_stream(const DeviceBatch& B, const int task_
         }
     }
     PHASE_END(3);
+    PHASE_FLUSH();
 }
 
 template <int K, int MODE>

@@ -1,7 +1,7 @@
 """Where a wave's cycles go in a region-sized call (one-haplotype fp32 pass): runs HaplotypeCaller-shaped regions one
-call each on the profiling build (make -C gatk_amd/csrc phase) and prints the per-phase share of wave cycles.  The
-build's counters are atomics on one address per phase: a global load that follows them in a wave (the termination's,
-before the per-read output base was fetched during set-up) waits for them to return, which inflates that phase."""
+call each on the profiling build (make -C gatk_amd/csrc phase) and prints the per-phase share of wave cycles.  A wave
+keeps its shares in registers and adds them to the build's counters when its work item is over (atomics in the middle
+of an item stood in front of the wave's later global loads and tripled the set-up's share)."""
 import ctypes
 import os
 import sys
