@@ -126,6 +126,16 @@ constexpr int kLutRowsPerRead = 4;
 constexpr int lut_row_pairs(int k) { return (k + kLutRowsPerRead - 1) / kLutRowsPerRead; }
 constexpr int kLutCodeStride = kWave * 4 * kLutRowsPerRead;  // bytes between two base codes of one row pair
 constexpr int lut_table_bytes(int k, int mode) { return is_lut(mode) ? lut_row_pairs(k) * lut_codes(mode) * kLutCodeStride : 0; }
+// The one-haplotype kernel up to kUnmaskedRows rows per lane (the values region-sized calls take) runs its whole sweep
+// without lane masks: its table has one more column, for the positions in front of and behind a haplotype, in which
+// every row's emission term is 0 except the sum row's, which is 1.  A lane that is not inside its haplotype yet then
+// recomputes column 0 (M = 0 stays 0, a pad row's deletion mass stays, the hand-offs are those of column 0), and a
+// lane that has left it lets its sum row take in what is still on its way (the sum row's M + E + waiting hand-off is
+// unchanged by such a step; the rows above it only produce values that go to lanes which have left as well).
+constexpr int kUnmaskedRows = 6;
+constexpr bool unmasked_sweep(int k, int mode) { return is_lut(mode) && k <= kUnmaskedRows; }
+constexpr int direct_lut_codes(int k, int mode) { return lut_codes(mode) + (unmasked_sweep(k, mode) ? 1 : 0); }
+constexpr int direct_table_bytes(int k, int mode) { return is_lut(mode) ? lut_row_pairs(k) * direct_lut_codes(k, mode) * kLutCodeStride : 0; }
 // index, in floats, of the table entry of row r against base code c for this lane
 __device__ __forceinline__ int lut_index(const int r, const int c, const int codes, const int lane) {
     return (((r / kLutRowsPerRead) * codes + c) * kWave + lane) * kLutRowsPerRead + (r % kLutRowsPerRead);
@@ -304,7 +314,7 @@ __device__ __forceinline__ void column_swapping(Rows<T, K>& w, const T (&prior)[
 // mode when every haplotype byte of the launch is one of those letters.
 template <int K, int MODE>
 struct Image {
-    static constexpr int kTableBytes = lut_table_bytes(K, MODE);
+    static constexpr int kTableBytes = direct_table_bytes(K, MODE);
 };
 
 // What a lane knows about its place in the wave-group.
@@ -457,6 +467,9 @@ __device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_id
     constexpr bool kScaled = IsScaled<T>::value;
     constexpr bool kLut = is_lut(MODE);
     constexpr int kCodes = lut_codes(MODE);
+    constexpr bool kUnmasked = unmasked_sweep(K, MODE);       // the whole sweep without lane masks, see direct_lut_codes
+    constexpr int kTblCodes = direct_lut_codes(K, MODE);      // columns of this kernel's table
+    constexpr unsigned kOutside = kCodes * kLutCodeStride;    // table offset of the column for positions outside the haplotype
     static_assert(!kLut || std::is_same<T, float>::value, "the emission table holds floats");
     PHASE_BEGIN();
     // ---- which wave-group and haplotype is this work item? (wave-uniform, scalar) ----------------
@@ -492,10 +505,13 @@ __device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_id
         const uint32_t* src = reinterpret_cast<const uint32_t*>(B.hap_pool + B.hap_off[hap_idx]);
         const int words = (H + 3) >> 2;
         if (kLut) {
-            // every entry the sweep can touch must hold a valid table offset: zero the pads
+            // every entry the sweep can touch must hold a valid table offset: the pads hold column 0, or, for the
+            // sweep without lane masks, the column for positions outside the haplotype (as do the entries behind
+            // base H - 1 in the haplotype's last word)
             uint16_t* img = reinterpret_cast<uint16_t*>(hap_img);
-            img[lane] = 0;
-            for (int d = lane; d < kHapBackPad; d += kWave) img[kHapFrontPad + words * 4 + d] = 0;
+            constexpr unsigned kPad = kUnmasked ? kOutside : 0u;
+            img[lane] = static_cast<uint16_t>(kPad);
+            for (int d = lane; d < kHapBackPad; d += kWave) img[kHapFrontPad + words * 4 + d] = static_cast<uint16_t>(kPad);
             uint2* dst = reinterpret_cast<uint2*>(img + kHapFrontPad);
             for (int d = lane; d < words; d += kWave) {
                 const uint32_t v = src[d];
@@ -504,6 +520,7 @@ __device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_id
                 for (int b = 0; b < 4; ++b) {
                     const unsigned byte = (v >> (8 * b)) & 0xffu;
                     c[b] = ((byte == 'N' && kCodes == 5) ? 4u : ((byte >> 1) & 3u)) * kLutCodeStride;
+                    if (kUnmasked && 4 * d + b >= H) c[b] = kOutside;
                 }
                 dst[d] = make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
             }
@@ -577,7 +594,8 @@ __device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_id
                 const unsigned letters[5] = {'A', 'C', 'T', 'G', 'N'};
 #pragma unroll
                 for (int c = 0; c < kCodes; ++c)
-                    tbl[lut_index(r, c, kCodes, lane)] = (XB[r] == letters[c] || c == 4) ? P[r] : Q[r];
+                    tbl[lut_index(r, c, kTblCodes, lane)] = (XB[r] == letters[c] || c == 4) ? P[r] : Q[r];
+                if (kUnmasked) tbl[lut_index(r, kCodes, kTblCodes, lane)] = (used && i == R + 1) ? 1.0f : 0.0f;  // outside the haplotype
             } else {
                 pin(XB[r]); pin(P[r]); pin(Q[r]);
             }
@@ -654,7 +672,8 @@ __device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_id
     int s = 0;
     // Every column of the sweep is a column_swapping of its step's parity (in the unrolled blocks, which start on even
     // steps, the parity is a constant): a lane whose first column is an odd step starts with M and E swapped.
-    if (ld.seg_lane & 1) {
+    // (A sweep without lane masks runs every lane through every step from step 0 on: nothing to swap.)
+    if (!kUnmasked && (ld.seg_lane & 1)) {
 #pragma unroll
         for (int r = 0; r < K; ++r) { const T e = w.El[r]; w.El[r] = w.Ml[r]; w.Ml[r] = e; }
     }
@@ -666,9 +685,47 @@ __device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_id
     if (kLut) {
         const uint16_t* hp = reinterpret_cast<const uint16_t*>(hap_img) + (kHapFrontPad - ld.seg_lane);
         const unsigned char* tbl_lane = slice + lane * 4 * kLutRowsPerRead;
-        auto emit = [&](const unsigned code_off, T (&prior)[K]) { lut_emit<T, K, kCodes>(tbl_lane, code_off, prior); };
+        auto emit = [&](const unsigned code_off, T (&prior)[K]) { lut_emit<T, K, kTblCodes>(tbl_lane, code_off, prior); };
         // reads issued a block ahead of their use; pinned in place where the wave is likely alone on its SIMD
-        auto emit_ahead = [&](const unsigned code_off, T (&prior)[K]) { lut_emit<T, K, kCodes, (K <= 6)>(tbl_lane, code_off, prior); };
+        auto emit_ahead = [&](const unsigned code_off, T (&prior)[K]) { lut_emit<T, K, kTblCodes, (K <= 6)>(tbl_lane, code_off, prior); };
+        if constexpr (kUnmasked) {
+            // One loop for fill, steady steps and drain: H + fill steps, every lane in every one of them; outside its
+            // haplotype a lane reads the table's extra column.  Eight steps per turn, the two sets of emission terms
+            // taking turns, reads a block ahead of their use.
+            const int end = H + fill;
+            T pa[4][K], pb[4][K];
+            unsigned yn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) emit_ahead(hp[u], pa[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) yn[u] = hp[4 + u];
+            auto block = [&](T (&cur)[4][K], T (&nxt)[4][K]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) emit_ahead(yn[u], nxt[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) yn[u] = hp[s + 8 + u];  // at most fill + 11 entries behind the haplotype: inside the back pad
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const T Sin = shr1(w.Sout);
+                    const T Iin = shr1(w.Iout);
+                    col(u, cur[u], Sin, Iin);
+                }
+                s += 4;
+            };
+            auto rest = [&](T (&cur)[4][K]) {  // the last 0 to 3 steps: their terms are in hand
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (s + u < end) {
+                        const T Sin = shr1(w.Sout);
+                        const T Iin = shr1(w.Iout);
+                        col(u, cur[u], Sin, Iin);
+                    }
+                s = end;
+            };
+            while (s + 8 <= end) { block(pa, pb); block(pb, pa); }
+            if (s + 4 <= end) { block(pa, pb); rest(pb); } else { rest(pa); }
+            PHASE_END(3);
+        }
         auto masked_step = [&](const int step) {
             const T Sin = shr1(w.Sout);
             const T Iin = shr1(w.Iout);
@@ -712,6 +769,7 @@ __device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_id
             }
             for (; s < end; ++s) masked_step(s);
         };
+        if constexpr (!kUnmasked) {
         masked_run(steady_begin);
         if (s & 1) { masked_step(s); ++s; }  // the steady blocks start on an even step
         PHASE_END(2);
@@ -766,6 +824,7 @@ __device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_id
         PHASE_END(3);
         masked_run(H + fill);
         PHASE_END(4);
+        }
     } else {
         const unsigned char* hp = hap_img + (kHapFrontPad - ld.seg_lane);
         auto emit = [&](const unsigned yb, T (&prior)[K]) {
@@ -1562,7 +1621,7 @@ hipError_t launch_finish_stream(const DeviceBatch& B, hipStream_t stream) {
 int lds_bytes_per_wave(int rows_per_lane, int emit_mode, int max_hap_len) {
     const int entries = kHapFrontPad + ((max_hap_len + 3) & ~3) + kHapBackPad;
     const bool lut = is_lut(emit_mode);
-    const int table = lut_table_bytes(rows_per_lane, emit_mode);
+    const int table = direct_table_bytes(rows_per_lane, emit_mode);
     return (table + entries * (lut ? 2 : 1) + 15) & ~15;
 }
 
