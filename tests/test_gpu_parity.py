@@ -74,6 +74,37 @@ def test_every_rows_per_lane_variant(hmm, oracle, k, stream_mode):
         hmm.set_option("stream_mode", 1)
 
 
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6])
+def test_sweep_without_lane_masks_on_short_and_ragged_shapes(hmm, oracle, k):
+    """Up to 6 rows per lane the one-haplotype table-mode kernel runs fill, steady steps and drain in one loop without
+    lane masks (a table column stands for the positions outside a haplotype).  Haplotypes shorter than the pipeline,
+    of 1 to 3 bases, of lengths around the four- and eight-step blocks, reads of every length a lane segment can hold,
+    several segments of different lengths in one wave-group."""
+    rng = np.random.default_rng(700 + k)
+    longest = min(64 * k - 2, 150)
+    reads = []
+    for n in [1, 2, 3, longest, longest - 1, max(1, longest // 2)] + [int(rng.integers(1, longest + 1)) for _ in range(34)]:
+        bases = rng.choice(list(b"ACGTN"), size=n, p=[0.24, 0.24, 0.24, 0.24, 0.04]).astype(np.uint8)
+        quals = rng.integers(2, 42, size=n).astype(np.uint8)
+        ins = rng.integers(1, 60, size=n).astype(np.uint8)
+        dele = rng.integers(1, 60, size=n).astype(np.uint8)
+        gcp = rng.integers(5, 30, size=n).astype(np.uint8)
+        reads.append((bases, quals, ins, dele, gcp))
+    for hap_lens in ([1, 2, 3], [4, 5, 7, 8, 9], [11, 12, 13, 15, 16, 17, 40], [63, 64, 65, 130, 131]):
+        haps = [rng.choice(list(b"ACGT"), size=n).astype(np.uint8) for n in hap_lens]
+        b = pack(reads, haps)
+        want = ref(oracle, b)
+        hmm.set_option("force_rows_per_lane", k)
+        hmm.set_option("stream_mode", 0)  # one haplotype per work item
+        try:
+            assert_parity(hmm.compute_batch(b), want)
+            st = hmm.stats()
+            assert st["main_rows_per_lane"] == k and st["main_stream_pass"] == 0 and st["main_emit_mode"] in (2, 3)
+        finally:
+            hmm.set_option("force_rows_per_lane", 0)
+            hmm.set_option("stream_mode", 1)
+
+
 def test_long_read_indel_stress_uses_the_fp64_rerun(hmm, oracle):
     b = synth.config_c5(num_reads=96, num_haps=8)
     got = hmm.compute_batch(b)
