@@ -13,7 +13,7 @@
 // along a row (the cell to the left, the best horizontal gap and its length) stays in the lane's
 // registers.  The alternate sequence sits in LDS.  The back-track matrix goes to global memory as int16
 // (a gap is never longer than a sequence) in the order it is produced, [step][row of the lane][lane], so
-// that the 64 lanes of a store write 128 consecutive bytes; a second kernel, one thread per pair, picks
+// that the 64 lanes of a store write 128 consecutive bytes; a second kernel, one wave per pair, picks
 // the end cell and walks the matrix through the same index map.  The host reverses and consolidates the
 // few CIGAR elements.
 //
@@ -231,12 +231,18 @@ __global__ void __launch_bounds__(kWave) sw_fill_packed(const SwArgs A, const in
     int32_t* const bottom = last_col + (n + 1);
     const int steps = m + (n + K - 1) / K - 1;
     const int last_row_lane = (n - 1) / K, last_row_r = (n - 1) % K;
+    // the alternate's base of a step is read a step ahead (a wave alone on its SIMD would wait out the LDS latency
+    // every step; volatile, or the compiler moves the read back to its use)
+    const volatile __attribute__((address_space(3))) uint8_t* const alt_of_lane =
+        (const volatile __attribute__((address_space(3))) uint8_t*)alt_lds + (kWave - lane);
+    int b_next = alt_of_lane[0];  // column 1 - lane: the pad in front for every lane but the first
     for (int s = 0; s < steps; ++s) {
         int up = shr1(out_sw), wv = shr1(out_wv);
         const int j = s - lane + 1;
+        const int b_base = b_next;
+        b_next = alt_of_lane[s + 1];  // column j + 1; behind the alternate: the pad (64 entries, and a lane is at most 63 columns behind lane 0)
         if (lane == 0) { up = edge_score(A, j) * unit; wv = none_v; }
         if (j >= 1 && j <= m) {
-            const int b_base = alt_lds[kWave + j - 1];
             const int up_in = up;
             int16_t* const bt_step = bt + static_cast<int64_t>(s) * K * kWave + lane;
             // everything that reads the previous column first (after it a row's old value is dead and the new one
@@ -279,10 +285,24 @@ __global__ void __launch_bounds__(kWave) sw_fill_packed(const SwArgs A, const in
     }
 }
 
-// calculateCigar, :350-470, one thread per pair: the raw element list (last element first) and the offset.
-__global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A, const int first_pair, const int num) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+// calculateCigar, :350-470, one wave per pair: the raw element list (last element first) and the offset.
+//
+// The reference's two scans for the end cell and its walk are sequential loops; a lane working through them alone makes
+// one trip to memory per handful of entries (a region-sized call spent 140 us here, as much as in the fill).  The wave
+// does the same work side by side:
+//   * last column (:362-372, "score >= best" keeps the LAST row among equal scores): every lane takes the rows
+//     lane + 1, lane + 65, ...; the lanes' bests are merged by (score, then larger row);
+//   * bottom row (:375-392: a column replaces the best so far when its score is higher, or equal and its cell strictly
+//     closer to the diagonal): the outcome of that loop is the least of (score descending, distance from the diagonal
+//     ascending, scan order ascending) over the last column's winner and all columns, so the lanes' bests merge by that key;
+//   * the walk (:401-430) runs mostly along diagonals: the 64 lanes fetch the next 64 cells of the diagonal, a ballot
+//     finds the first that is not a diagonal step, and all lanes keep the same walk state (lane 0 writes the elements).
+__device__ __forceinline__ int wave_first_lane_value(int v, int src_lane) { return __shfl(v, src_lane, kWave); }
+
+__global__ void __launch_bounds__(kWave) sw_backtrack(const SwArgs A, const int first_pair, const int num) {
+    const int x = blockIdx.x;
     if (x >= num) return;
+    const int lane = threadIdx.x;
     const int k = A.order[first_pair + x];
     const PairDesc P = A.pairs[k];
     const int refLength = P.n, altLength = P.m;
@@ -293,8 +313,10 @@ __global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A, const int fir
     int32_t* heads = A.heads + static_cast<int64_t>(k) * 2 * kHeadElems;
     int count = 0;
     auto add = [&](int op, int len) {
-        if (count < P.elem_cap) { elems[2 * count] = op; elems[2 * count + 1] = len; }
-        if (count < kHeadElems) { heads[2 * count] = op; heads[2 * count + 1] = len; }
+        if (lane == 0) {
+            if (count < P.elem_cap) { elems[2 * count] = op; elems[2 * count + 1] = len; }
+            if (count < kHeadElems) { heads[2 * count] = op; heads[2 * count + 1] = len; }
+        }
         ++count;
     };
     // A packed entry is the low 16 bits of the winning word: length in the low len_bits bits, the priority (2 diagonal,
@@ -307,55 +329,52 @@ __global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A, const int fir
         p1 = refLength; p2 = altLength;
     } else {
         p2 = altLength;
-        // the two scans of :362-392, their loads fetched kScan at a time (the comparisons stay in order)
-        constexpr int kScan = 16;
-        for (int i0 = 1; i0 <= refLength; i0 += kScan) {
-            int cur[kScan];
+        {   // last column
+            int best_v = INT_MIN, best_i = 0;
+            for (int i = 1 + lane; i <= refLength; i += kWave) {
+                const int v = last_col[i];
+                if (v >= best_v) { best_v = v; best_i = i; }
+            }
 #pragma unroll
-            for (int q = 0; q < kScan; ++q) cur[q] = i0 + q <= refLength ? last_col[i0 + q] : INT_MIN;
-#pragma unroll
-            for (int q = 0; q < kScan; ++q)
-                if (i0 + q <= refLength && cur[q] >= maxscore) { p1 = i0 + q; maxscore = cur[q]; }
+            for (int off = kWave / 2; off > 0; off >>= 1) {
+                const int ov = __shfl_xor(best_v, off, kWave), oi = __shfl_xor(best_i, off, kWave);
+                if (oi > 0 && (best_i == 0 || ov > best_v || (ov == best_v && oi > best_i))) { best_v = ov; best_i = oi; }
+            }
+            p1 = best_i; maxscore = best_v;  // refLength >= 1: some row always wins
         }
         if (A.strategy != GATK_SW_LEADING_INDEL) {
-            for (int j0 = 1; j0 <= altLength; j0 += kScan) {
-                int cur[kScan];
+            // candidates: columns 1 .. altLength of the bottom row; key (score descending, distance ascending, column ascending)
+            int best_v = INT_MIN, best_d = INT_MAX, best_j = 0;
+            for (int j = 1 + lane; j <= altLength; j += kWave) {
+                const int v = bottom[j], d = abs(refLength - j);
+                if (best_j == 0 || v > best_v || (v == best_v && d < best_d)) { best_v = v; best_d = d; best_j = j; }
+            }
 #pragma unroll
-                for (int q = 0; q < kScan; ++q) cur[q] = j0 + q <= altLength ? bottom[j0 + q] : INT_MIN;
-#pragma unroll
-                for (int q = 0; q < kScan; ++q) {
-                    const int j = j0 + q;
-                    if (j <= altLength && (cur[q] > maxscore || (cur[q] == maxscore && abs(refLength - j) < abs(p1 - p2)))) {
-                        p1 = refLength; p2 = j; maxscore = cur[q];
-                        segment_length = altLength - j;
-                    }
-                }
+            for (int off = kWave / 2; off > 0; off >>= 1) {
+                const int ov = __shfl_xor(best_v, off, kWave), od = __shfl_xor(best_d, off, kWave), oj = __shfl_xor(best_j, off, kWave);
+                const bool better = oj > 0 && (best_j == 0 || ov > best_v || (ov == best_v && (od < best_d || (od == best_d && oj < best_j))));
+                if (better) { best_v = ov; best_d = od; best_j = oj; }
+            }
+            // against the last column's winner, which came first in the reference's order
+            if (best_j > 0 && (best_v > maxscore || (best_v == maxscore && best_d < abs(p1 - p2)))) {
+                p1 = refLength; p2 = best_j; maxscore = best_v;
+                segment_length = altLength - best_j;
             }
         }
     }
     if (segment_length > 0 && A.strategy == GATK_SW_SOFTCLIP) { add(GATK_SW_OP_S, segment_length); segment_length = 0; }
     int state = GATK_SW_OP_M;
-    // The walk is a chain of dependent loads, and most of it runs along diagonals (matches): the next
-    // kAhead cells of the diagonal are fetched together, the leading zeros among them are that many match
-    // steps at once, the first non-zero one is a gap handled as in the reference's loop (:401-430).
-    constexpr int kAhead = 8;
     // every round moves at least one cell towards row 0 or column 0; the bound only keeps a damaged matrix from
     // holding the wave forever
     int rounds_left = refLength + altLength + 1;
     do {
-        const int span = min(kAhead, min(p1, p2));
-        int ahead[kAhead];
-#pragma unroll
-        for (int q = 0; q < kAhead; ++q) ahead[q] = q < span ? bt[btrack_index(p1 - q, p2 - q, P.rows_per_lane)] : diag_code;
-        int matches = 0, raw = 0;
-        bool gap = false;
-#pragma unroll
-        for (int q = 0; q < kAhead; ++q)
-            if (!gap && q < span) {
-                if ((ahead[q] & diag_mask) == diag_code) matches = q + 1; else { gap = true; raw = ahead[q]; }
-            }
-        int btr = 0;  // the reference's btrack value of the gap: > 0 that many rows up, < 0 that many columns left
-        if (gap) {
+        const int span = min(kWave, min(p1, p2));
+        const int raw_mine = lane < span ? bt[btrack_index(p1 - lane, p2 - lane, P.rows_per_lane)] : diag_code;
+        const unsigned long long not_diag = __ballot(lane < span && (raw_mine & diag_mask) != diag_code);
+        const int matches = not_diag ? __builtin_ctzll(not_diag) : span;  // leading diagonal steps
+        int btr = 0;  // the reference's btrack value of the gap behind them: > 0 that many rows up, < 0 that many columns left
+        if (not_diag) {
+            const int raw = wave_first_lane_value(raw_mine, matches);
             if (len_bits == 0) btr = raw;
             else { const int len = raw & ((1 << len_bits) - 1); btr = ((raw >> len_bits) & 3) == 1 ? -len : len; }
         }
@@ -386,7 +405,7 @@ __global__ void __launch_bounds__(64) sw_backtrack(const SwArgs A, const int fir
         else if (p2 > 0) add(GATK_SW_OP_I, p2);
         offset = 0;
     }
-    A.results[k] = PairResult{count, offset};
+    if (lane == 0) A.results[k] = PairResult{count, offset};
 }
 
 thread_local std::string g_sw_error;
@@ -652,7 +671,7 @@ int gatk_sw_align(int32_t device, int32_t num_pairs, const uint8_t* const* refer
         SW_TRY(hipStreamWaitEvent(stream, sc->join[k], 0));
     }
     // one back-track launch behind all fills (run next to them it slows them more than it gains)
-    hipLaunchKernelGGL(sw_backtrack, dim3((num_pairs + 63) / 64), dim3(64), 0, stream, A, 0, num_pairs);
+    hipLaunchKernelGGL(sw_backtrack, dim3(num_pairs), dim3(kWave), 0, stream, A, 0, num_pairs);
     SW_TRY(hipGetLastError());
     // Raw element lists: alignments of haplotypes have a handful of elements, so the first kHeadElems of every
     // pair come back packed in one copy and the rest of the few longer lists afterwards.
