@@ -418,8 +418,17 @@ int choose_rows_per_lane(const std::vector<int>& lens_desc, int64_t num_haps, do
 // items (one wave-group on one haplotype) number at most two per SIMD, a wave issues at the rate of a wave
 // alone, so the value with the shortest wave wins, which is the smallest that still has so few items; once
 // no value has so few, the one with the fewest vector instructions in total wins.
+// A call of fewer pairs than this per wave slot of the device goes through the one-haplotype pass (measured with the
+// one-haplotype kernel of up to 6 rows per lane against haplotype runs: 16 regions 147 against 157 us, 32 regions 310
+// against 317 us, equal from 128 regions, runs ahead beyond: 1000 regions 4.7 against 5.4 ms).
+constexpr int kRunsFromPairsPerSlot = 4;
 struct RegionShape { int num_reads, num_haps; double packing_read_len, mean_hap_len; };
-int choose_call_rows_per_lane(const std::vector<RegionShape>& shapes, int longest_read) {
+// one_haplotype_pass: the call is too small for haplotype runs and goes through the one-haplotype kernel, whose
+// instantiations up to 6 rows per lane keep their table reads a block ahead and sweep without lane masks (measured
+// about a quarter faster per instruction than the others on such calls).  There the choice is by modelled time: the
+// vector instructions of an average wave, times how many waves a SIMD gets beyond the two that issue at a lone wave's
+// rate.  (Calls of 8 to 12 regions: 5 rows per lane instead of 7 or 8, 128 -> 116 us at 12 regions.)
+int choose_call_rows_per_lane(const std::vector<RegionShape>& shapes, int longest_read, bool one_haplotype_pass) {
     const int min_k = (longest_read + 1 + kWave) / kWave;
     int best_k = 0;
     double best = std::numeric_limits<double>::infinity();
@@ -433,6 +442,11 @@ int choose_call_rows_per_lane(const std::vector<RegionShape>& shapes, int longes
             const double w = static_cast<double>((r.num_reads + per_wave - 1) / per_wave) * r.num_haps;
             items += w;
             work += w * (r.mean_hap_len + seg + 1) * (5.0 * k + 6.0);
+        }
+        if (one_haplotype_pass) {
+            const double time = work / std::max(items, 1.0) * std::max(1.0, items / (2.1 * 1024)) * (k > 6 ? 1.25 : 1.0);
+            if (time < best * 0.99) { best = time; best_k = k; }
+            continue;
         }
         if (items <= 2.1 * 1024) return k;
         if (work < best * 0.99) { best = work; best_k = k; }
@@ -729,7 +743,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             shapes.push_back(RegionShape{nonempty, b.num_haps, 0.5 * (mean_len + region_longest),
                                          static_cast<double>(b.hap_offsets[b.num_haps] - b.hap_offsets[0]) / b.num_haps});
         }
-        call_k = choose_call_rows_per_lane(shapes, longest);
+        call_k = choose_call_rows_per_lane(shapes, longest, h->stream_mode == 0 || (h->stream_mode < 0 && call_pairs < kRunsFromPairsPerSlot * static_cast<int64_t>(h->wave_slots)));
     }
 
     PLAN_CLOCK(0);
@@ -883,7 +897,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         // Haplotype runs (the stream pass), unless the call is too small to give any wave a run: it then takes
         // the one-haplotype pass, which writes log10 results itself - one kernel less on a call whose time is
         // the chain of its launches.
-        const bool runs = h->stream_mode > 0 || (h->stream_mode < 0 && call_pairs >= 2 * static_cast<int64_t>(h->wave_slots));
+        const bool runs = h->stream_mode > 0 || (h->stream_mode < 0 && call_pairs >= kRunsFromPairsPerSlot * static_cast<int64_t>(h->wave_slots));
         if (!any_hap_other && h->emit_mode != 0) {
             const int lut = any_hap_n ? kEmitLut5 : kEmitLut4;
             // a workgroup's LDS must fit the 64 KiB a block may ask for; the stream pass keeps only the table

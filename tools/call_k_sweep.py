@@ -5,7 +5,9 @@ import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gatk_amd import pairhmm, synth
+options = [(a.split("=")[0], float(a.split("=")[1])) for a in sys.argv[1:] if "=" in a]  # engine options for every handle
 regions = synth.make_regions(256, seed=5)
+print("options:", options or "defaults")
 lib = pairhmm.load_library()
 for n in (4, 8, 12, 16, 24, 32, 48, 64, 128):
     g = regions[:n]
@@ -17,6 +19,8 @@ for n in (4, 8, 12, 16, 24, 32, 48, 64, 128):
     for k in (0, 3, 4, 5, 6, 8, 10):
         h = pairhmm.HipLoglessPairHMM(0)
         h.set_option("force_rows_per_lane", k)
+        for name, value in options:
+            h.set_option(name, value)
         for _ in range(10):
             assert lib.gatk_pairhmm_compute_regions(h._h, n, cbs, arr) == 0
         ts = []
