@@ -1,7 +1,7 @@
 // Region-at-a-time calls from T host threads, one handle per thread (how the reference's map threads would
 // drive a PairHMM, nanoScheduler/NanoScheduler.java:112 and pairhmm/PairHMM.java:297), with and without the
 // handle option "combine_calls".  Synthetic HaplotypeCaller-sized regions: 30-100 reads of 121-151 bases,
-// 2-16 haplotypes of 250-500 bases.  usage: thread_bench REGIONS THREADS COMBINE(0|1)
+// 2-16 haplotypes of 250-500 bases.  usage: thread_bench REGIONS THREADS COMBINE(0|1) [OPTION VALUE ...]
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -62,6 +62,7 @@ int main(int argc, char** argv) {
     for (auto& h : handles) {
         if (gatk_pairhmm_create(0, &h)) { std::printf("%s\n", gatk_pairhmm_last_error()); return 1; }
         gatk_pairhmm_set_option(h, "combine_calls", combine);
+        for (int a = 4; a + 1 < argc; a += 2) gatk_pairhmm_set_option(h, argv[a], std::atof(argv[a + 1]));  // further engine options: NAME VALUE ...
     }
     double best = 1e30;
     for (int rep = 0; rep < 4; ++rep) {  // the first repetition warms buffers and clocks
