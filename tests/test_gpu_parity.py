@@ -789,6 +789,29 @@ def test_region_sized_call_on_a_default_handle(oracle):
         h.close()
 
 
+def test_small_results_come_home_the_same_through_flag_event_and_copy():
+    """A region-sized result reaches the caller through one block that raises a flag in pinned host memory, through a
+    copy kernel and an event, or through the runtime's copy: the same doubles every way, call after call on one handle
+    (the flag's sequence number moves on), results of different sizes in turn, an input error in between."""
+    regions = synth.make_regions(6, seed=77, coverage=25, read_len=140) + [synth.config_c1()]
+    h = pairhmm.HipLoglessPairHMM(0)
+    try:
+        got = {}
+        for name, opts in (("flag", {}), ("event", {"signal_download_bytes": 0}), ("copy", {"signal_download_bytes": 0, "kernel_download_bytes": 0})):
+            h.set_option("signal_download_bytes", opts.get("signal_download_bytes", 65536))
+            h.set_option("kernel_download_bytes", opts.get("kernel_download_bytes", 524288))
+            got[name] = [h.compute_batch(b).copy() for _ in range(3) for b in regions][-len(regions):]
+            with pytest.raises(pairhmm.ArrayIndexOutOfBoundsException):
+                h.compute_batch(pack([("ACGT", [30, 255, 30, 30], [45] * 4, [45] * 4, [10] * 4)], ["ACGTA"]))
+            again = h.compute_batch(regions[0])
+            assert np.array_equal(again, got[name][0])
+        for name in ("event", "copy"):
+            for a, b in zip(got["flag"], got[name]):
+                assert np.array_equal(a, b), name
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("num_regions", [10, 40, 70])
 def test_mid_sized_calls_on_a_default_handle(oracle, num_regions):
     """Calls of some thousand to some ten thousand pairs on a handle with default options: one rows-per-lane
