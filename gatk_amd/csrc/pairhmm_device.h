@@ -14,7 +14,7 @@ inline bool rows_per_lane_supported(int k) {
 }
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
-constexpr int kInlineRerunRows = 4;  // up to this many rows per lane the fp32 one-haplotype pass redoes an item in fp64 itself
+constexpr int kInlineRerunRows = 5;  // up to this many rows per lane the fp32 one-haplotype pass redoes an item in fp64 itself
 constexpr int kHapFrontPad = 64;  // entries in front of the LDS haplotype image: lanes ahead of column 1 read here
 constexpr int kHapBackPad = 80;   // entries behind it: draining lanes and the read-ahead of the sweep land here
 
