@@ -329,6 +329,7 @@ struct gatk_pairhmm {
     unsigned done_seq = 0;                             // value the next such download stores there
     int64_t per_group_factor = 32;  // calls with at least this many pairs per wave slot choose rows per lane per wave-group
     bool combine_calls = false;  // small compute_likelihoods calls of all threads on this device share device passes
+    int combine_from_callers = 4;  // ... once this many such calls are under way on the device; fewer run alone on their own handles
     bool pipeline_ramp = true;  // the first two parts of a cut call are a quarter and a half of pipeline_pairs
     int stream_lds_floor = 0;  // least LDS bytes per wave of the stream pass (caps the waves a CU holds)
     double* d_err = nullptr;
@@ -1851,6 +1852,8 @@ void run_combined(gatk_pairhmm* engine, const std::vector<Combiner::Request*>& r
     }
 }
 
+std::atomic<int> g_small_calls_under_way[64];  // per device (index & 63): compute_likelihoods calls of combining handles in progress
+
 int compute_combined(int device, bool squash, const gatk_pairhmm_batch* batch, double* out) {
     Combiner* c = combiner_for(device, squash);
     Combiner::Request mine{batch, out};
@@ -1945,14 +1948,25 @@ int gatk_pairhmm_compute_likelihoods(gatk_pairhmm* h, const gatk_pairhmm_batch* 
     // combined: a call that cannot fill the device by itself, on a handle whose other options are the defaults
     const bool plain = h->fp32_threshold == 1e-28f && h->force_rows_per_lane == 0 && !h->force_fp64 && h->emit_mode == -1 &&
                        h->stream_mode == -1 && !h->timing && !h->no_tristate_correction;
+    bool combined = false;
     if (h->combine_calls && h->children.empty() && plain && n < 4 * static_cast<int64_t>(h->wave_slots)) {
-        int read_max = 0, hap_max = 0;
-        if (int rc = check_region(*batch, 0, &read_max, &hap_max)) return rc;
-        if (int rc = compute_combined(h->device, h->squash_base_quals, batch, likelihoods)) return rc;
-        h->stats = gatk_pairhmm_stats{};
-        h->stats.pairs = n;
-        note_call_maxima(h, *batch, read_max, hap_max);
+        // With few callers on the device at this moment a call is better off alone on its own handle (4 threads: 16.5 us
+        // per region alone, 21 through the shared engines, of which there are three); from the fifth caller under way
+        // the calls share passes.
+        std::atomic<int>& under_way = g_small_calls_under_way[h->device & 63];
+        const int before_me = under_way.fetch_add(1, std::memory_order_acq_rel);
+        struct Leave { std::atomic<int>& n; ~Leave() { n.fetch_sub(1, std::memory_order_acq_rel); } } leave{under_way};
+        if (before_me >= h->combine_from_callers) {
+            int read_max = 0, hap_max = 0;
+            if (int rc = check_region(*batch, 0, &read_max, &hap_max)) return rc;
+            if (int rc = compute_combined(h->device, h->squash_base_quals, batch, likelihoods)) return rc;
+            h->stats = gatk_pairhmm_stats{};
+            h->stats.pairs = n;
+            note_call_maxima(h, *batch, read_max, hap_max);
+            combined = true;
+        } else if (int rc = gatk_pairhmm_compute_regions(h, 1, batch, outs)) return rc;
     } else if (int rc = gatk_pairhmm_compute_regions(h, 1, batch, outs)) return rc;
+    (void)combined;
     h->likelihood_array.assign(likelihoods, likelihoods + n);  // mLikelihoodArray, PairHMM.java:206,225
     return GATK_PAIRHMM_OK;
 } catch (...) { return on_exception(); }
@@ -2137,6 +2151,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) try
     else if (n == "pipeline_depth") h->pipeline_depth = value >= 3 ? 3 : 2;
     else if (n == "pipeline_min_pairs") h->pipeline_min_pairs = std::max<int64_t>(1, static_cast<int64_t>(value));
     else if (n == "combine_calls") h->combine_calls = value != 0;
+    else if (n == "combine_from_callers") h->combine_from_callers = std::max(0, static_cast<int>(value));
     else if (n == "per_group_factor") h->per_group_factor = std::max<int64_t>(1, static_cast<int64_t>(value));
     else if (n == "kernel_download_bytes") h->kernel_download_bytes = static_cast<size_t>(std::max(0.0, value));
     else if (n == "signal_download_bytes") h->signal_download_bytes = static_cast<size_t>(std::max(0.0, value));

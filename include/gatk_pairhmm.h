@@ -205,6 +205,9 @@ int gatk_pairhmm_device_count(int32_t* count);
  *                         call through one device pass, its own included, the others wait for their results;
  *                         same results and exceptions, per caller; only on handles whose other options are
  *                         the defaults, squash_base_quals aside.
+ *   "combine_from_callers" default 4: with combine_calls on, a call shares passes only when at least this many such
+ *                         calls are already under way on the device; with fewer it runs alone on its own handle
+ *                         (2 to 8 caller threads are 5 to 20 % faster that way, 16 and more 5 % slower).  0: always share.
  *   "kernel_upload_bytes" default 1048576: an upload of at most that many bytes is copied out of the pinned
  *                         staging buffer by a kernel on the compute stream instead of by the DMA engine, whose
  *                         hand-over to the first kernel costs more than the copy of a region-sized call.
