@@ -2,55 +2,10 @@
 // error behaviour, the host-side planner that turns region batches into wavefront tasks, device
 // buffer management and kernel sequencing.  There is no CPU compute path in this file: every
 // likelihood comes out of the HIP kernels, and handle creation fails when no device is present.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <emmintrin.h>
-
-#include <array>
-#include <functional>
-#include <thread>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <condition_variable>
-#include <deque>
-#include <map>
-#include <memory>
-#include <new>
-#include <stdexcept>
-#include <mutex>
-#include <cstdio>
-#include <cstring>
-#include <limits>
-#include <numeric>
-#include <string>
-#include <vector>
-
-#include "../../include/gatk_pairhmm.h"
-#include "pairhmm_device.h"
-#include "pairhmm_tables.h"
-
-namespace pairhmm_hip {
-hipError_t launch_forward(const DeviceBatch& B, int rows_per_lane, int emit_mode, bool fp64, bool list_mode,
-                          int blocks, hipStream_t stream);
-int lds_bytes_per_wave(int rows_per_lane, int emit_mode, int max_hap_len);
-int stream_lds_bytes_per_wave(int rows_per_lane, int emit_mode);
-hipError_t launch_stream(const DeviceBatch& B, int rows_per_lane, int emit_mode, hipStream_t stream);
-hipError_t launch_finish_stream(const DeviceBatch& B, hipStream_t stream);
-hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int waves, hipStream_t stream);
-hipError_t launch_normalize_reads(const DeviceBatch& B, const int32_t* reference_allele_index, int best_to_zero, double cap, hipStream_t stream);
-hipError_t launch_flag_poorly_modelled_reads(const DeviceBatch& B, double maximum_error_per_base, uint8_t* flags, hipStream_t stream);
-hipError_t launch_marginalize_reads(const DeviceBatch& B, const int32_t* old_to_new, const int64_t* new_base, const int32_t* new_count,
-                                    double* new_out, hipStream_t stream);
-hipError_t launch_prepare(const DeviceBatch& B, bool expand_rows, bool stream, hipStream_t s);
-hipError_t launch_upload(const void* pinned_host, void* device, size_t bytes, hipStream_t s);
-hipError_t launch_download(void* device, void* pinned_host, size_t bytes, size_t clear_bytes, hipStream_t s);
-hipError_t launch_download_and_signal(void* device, void* pinned_host, size_t bytes, size_t clear_bytes, unsigned* pinned_flag,
-                                      unsigned seq, hipStream_t s);
-}  // namespace pairhmm_hip
+#include "pairhmm_engine.h"
 
 using namespace pairhmm_hip;
+using namespace pairhmm_host;
 
 // ---------------------------------------------------------------------------------------------
 // Working memory of gatk_pairhmm_compute_likelihoods_noalloc, the entry point for callers that cannot
@@ -96,31 +51,6 @@ struct RegionCallCount {
     ~RegionCallCount() { n.fetch_sub(1); }
 };
 
-int fail(int code, const std::string& msg) {
-    g_last_error = msg;
-    return code;
-}
-
-// The handler of every entry point: no C++ exception (a failed host allocation, a thread that cannot be
-// started) crosses the C boundary into a caller that cannot unwind it.
-int on_exception() noexcept {
-    try {
-        try { throw; }
-        catch (const std::bad_alloc&) { return fail(GATK_PAIRHMM_OUT_OF_MEMORY, "host memory exhausted"); }
-        catch (const std::exception& e) { return fail(GATK_PAIRHMM_DEVICE_ERROR, std::string("internal error: ") + e.what()); }
-        catch (...) { return fail(GATK_PAIRHMM_DEVICE_ERROR, "internal error: unknown exception"); }
-    } catch (...) {
-        return GATK_PAIRHMM_OUT_OF_MEMORY;  // not even the message could be stored
-    }
-}
-
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess)                                                                           \
-            return fail(e_ == hipErrorOutOfMemory ? GATK_PAIRHMM_OUT_OF_MEMORY : GATK_PAIRHMM_DEVICE_ERROR, \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                             \
-    } while (0)
 
 // Address of `scratch` on each device, filled once per device by setup_scratch with that device current.
 constexpr int kMaxScratchDevices = 64;
@@ -138,237 +68,32 @@ int setup_scratch(int device) {
     return GATK_PAIRHMM_OK;
 }
 
-// Grow-only device buffer.
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        if (p) {
-            hipError_t e = hipFree(p);
-            p = nullptr; cap = 0;
-            if (e != hipSuccess) return e;
-        }
-        size_t want = bytes + bytes / 4 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-    }
-    template <typename T> T* as() const { return static_cast<T*>(p); }
-};
-
-// Grow-only pinned host buffer (staging for the one H2D and the one D2H copy of a call).
-struct PinnedBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    // coherent: fine-grained whatever the process environment says about the default, for memory the host reads
-    // while the kernel that writes it is still running (download_and_signal)
-    hipError_t ensure(size_t bytes, bool coherent = false) {
-        if (bytes <= cap) return hipSuccess;
-        if (p) {
-            hipError_t e = hipHostFree(p);
-            p = nullptr; cap = 0;
-            if (e != hipSuccess) return e;
-        }
-        size_t want = bytes + bytes / 2 + 4096;
-        hipError_t e = hipHostMalloc(&p, want, coherent ? hipHostMallocCoherent : hipHostMallocDefault);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    // the same, keeping the first `keep` bytes of what the buffer holds
-    hipError_t ensure_keep(size_t bytes, size_t keep) {
-        if (bytes <= cap) return hipSuccess;
-        void* old = p;
-        p = nullptr; cap = 0;
-        hipError_t e = ensure(bytes);
-        if (e == hipSuccess && old && keep) memcpy(p, old, keep);
-        if (old) { const hipError_t f = hipHostFree(old); if (e == hipSuccess) e = f; }
-        return e;
-    }
-    void release() {
-        if (p) (void)hipHostFree(p);
-        p = nullptr; cap = 0;
-    }
-};
-
-constexpr size_t kCounterBytes = 256;  // device counters of a pass: error word, rerun-list lengths, pair-list lengths, first bad read
-constexpr int kErrorReadSlot = 1 + 2 * kMaxBuckets;  // counters[kErrorReadSlot]: INT32_MAX - index of the first read with an input error, 0 = none
-static_assert((kErrorReadSlot + 1) * sizeof(int32_t) <= kCounterBytes, "counter block");
-
-struct Bucket {
-    int rows_per_lane = 0;
-    int task_begin = 0;   // offset of this bucket in the rerun-list array
-    int num_tasks = 0;
-    int desc_begin = 0;   // first RegionDesc of this bucket
-    int num_descs = 0;
-    int max_hap_len = 0;
-    int emit_mode = kEmitCompare;       // fp32 pass
-    int emit_mode_fp64 = kEmitCompare;  // fp64 pass: always compares bytes
-    // fp32 stream pass (table modes only): haplotype runs instead of single haplotypes
-    bool stream = false;
-    int stream_desc_begin = 0, num_stream_descs = 0, num_stream_tasks = 0;
-    int64_t pair_begin = 0, num_pairs = 0;  // its part of the list of pairs queued for the fp64 pair pass
-    int pair_rows_per_lane = 1;             // rows per lane of the fp64 pair pass (its own choice, see plan)
-    int slot_lanes = 1;                     // lanes a pair gets there
-};
-
 }  // namespace
 
-struct gatk_pairhmm_resident {
-    // ---- host-side plan ----
-    hipStream_t stream = nullptr;  // every copy and kernel of this batch is ordered on it
-    int num_regions = 0;
-    int region_label_base = 0;       // index, in the caller's region list, of this batch's first region (error messages)
-    bool regions_are_pieces = false; // the call cut large regions by read ranges: indices count the pieces
-    std::vector<int64_t> region_out_off;  // [num_regions + 1] offsets into the concatenated output
-    int64_t total_pairs = 0, cells = 0, total_tasks = 0;
-    int64_t total_read_bytes = 0;
-    std::vector<Bucket> buckets;
-    std::vector<RegionDesc> descs;      // as uploaded, bucket by bucket
-    std::vector<uint8_t> group_segs;    // reads packed in each wave-group
-    int32_t num_neg_inf = 0;            // output slots of zero-length reads
-    bool computed = false;
-    double plan_ms = 0, upload_ms = 0;
-    // ---- device ----
-    DevBuf d_arena;  // every input array of the call, one H2D copy
-    // d_out: [kCounterBytes of counters][likelihoods]: one device-to-host copy fetches both
-    DevBuf d_out, d_rerun_lists;
-    int32_t* counters() const { return d_out.as<int32_t>(); }
-    double* out() const { return reinterpret_cast<double*>(d_out.as<uint8_t>() + kCounterBytes); }
-    DevBuf d_row_consts;  // fp32 row constants of every read, written on the device
-    DevBuf d_hap_stream, d_raw_out, d_pair_lists;  // fp32 stream pass and the fp64 pair pass behind it
-    size_t hap_stream_entries = 0;
-    std::vector<int32_t> region_reads, region_haps;     // per region of the call (0 haplotypes when it has no reads)
-    std::vector<int32_t> region_read_begin, region_hap_begin;  // global index of a region's first read / haplotype
-    int64_t total_reads = 0, total_haps = 0;
-    DevBuf d_epilogue;  // small arrays of the steps behind the path: per-region parameters, flags, marginal likelihoods
-    bool any_stream = false;
-    bool streamed = false;  // the last pass enqueued used the stream pass and the fp64 pair pass
-    DeviceBatch base{};  // pointers into d_arena
-    bool counters_clear = false;        // the counters were zeroed behind the last download: the next pass need not
-    hipEvent_t ev_downloaded = nullptr; // recorded behind a download's device-to-host copy
-    // HIP events of the passes enqueued since the last wait (timing option): start, forward kernels
-    // begin / end, fp64 pass begin, end
-    using EventSet = std::array<hipEvent_t, 5>;
-    std::vector<EventSet> ev_pending, ev_free;
-    gatk_pairhmm_stats last_timing{};
-    void release() {
-        for (DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_row_consts, &d_hap_stream, &d_raw_out, &d_pair_lists, &d_epilogue}) b->release();
-        counters_clear = false;
-        if (ev_downloaded) (void)hipEventDestroy(ev_downloaded);
-        ev_downloaded = nullptr;
-        for (auto* v : {&ev_pending, &ev_free}) {
-            for (auto& set : *v)
-                for (auto& e : set)
-                    if (e) (void)hipEventDestroy(e);
-            v->clear();
-        }
-    }
-};
+namespace pairhmm_host {
 
-// One host thread of a multi-device handle: runs the jobs it is given one at a time on its own device's engine.
-struct DeviceWorker {
-    std::thread th;
-    std::mutex m;
-    std::condition_variable cv;
-    std::function<void()> job;
-    bool has_job = false, done = true, stop = false;
-    void start() { th = std::thread([this] { loop(); }); }
-    void loop() {
-        std::unique_lock<std::mutex> lk(m);
-        for (;;) {
-            cv.wait(lk, [&] { return has_job || stop; });
-            if (!has_job) return;  // stop
-            std::function<void()> j = std::move(job);
-            has_job = false;
-            lk.unlock();
-            j();
-            lk.lock();
-            done = true;
-            cv.notify_all();
-        }
-    }
-    void submit(std::function<void()> j) {
-        { std::lock_guard<std::mutex> lk(m); job = std::move(j); has_job = true; done = false; }
-        cv.notify_all();
-    }
-    void wait() {
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return done; });
-    }
-    void shutdown() {
-        { std::lock_guard<std::mutex> lk(m); stop = true; }
-        cv.notify_all();
-        if (th.joinable()) th.join();
-    }
-};
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
 
-struct gatk_pairhmm {
-    // A multi-device handle (gatk_pairhmm_create_multi) owns one single-device engine per entry of its device
-    // list and computes nothing itself: its compute calls shard regions over the engines.  children[0] runs on
-    // the calling thread, children[k > 0] on workers[k - 1].
-    std::vector<gatk_pairhmm*> children;
-    std::vector<std::unique_ptr<DeviceWorker>> workers;
-    unsigned next_child = 0;     // small calls go to the engines in turn
-    bool stats_in_first_engine = false;  // the last call went through the resident interface, which the first engine serves
-    int64_t multi_min_pairs = 8192;  // a call with fewer pairs goes to one engine on the calling thread
-    bool is_shared_engine = false;  // an engine of the call combiner, not a caller's handle
-    bool counted = false;           // counted among the live callers' handles (see release_shared_engines_if_last)
-    int device = 0;
-    hipStream_t stream = nullptr;
-    int wave_slots = 3072;  // waves the device holds at once at three per SIMD
-    size_t kernel_upload_bytes = size_t{1} << 20;  // uploads up to this size are copied by a kernel, not by the DMA engine
-    size_t kernel_download_bytes = size_t{512} << 10;  // results of at most this many bytes are copied back by a kernel
-    size_t signal_download_bytes = size_t{64} << 10;   // ... and of at most this many by one block that then raises a flag the host polls
-    PinnedBuf done_flag;                               // that flag (one word of pinned host memory)
-    PinnedBuf signal_out;                              // and where such a result lands (coherent pinned memory)
-    unsigned done_seq = 0;                             // value the next such download stores there
-    int64_t per_group_factor = 32;  // calls with at least this many pairs per wave slot choose rows per lane per wave-group
-    bool combine_calls = false;  // small compute_likelihoods calls of all threads on this device share device passes
-    int combine_from_callers = 4;  // ... once this many such calls are under way on the device; fewer run alone on their own handles
-    bool pipeline_ramp = true;  // the first two parts of a cut call are a quarter and a half of pipeline_pairs
-    int stream_lds_floor = 0;  // least LDS bytes per wave of the stream pass (caps the waves a CU holds)
-    double* d_err = nullptr;
-    double* d_mm = nullptr;
-    bool initialized = false;
-    int max_read = 0, max_hap = 0;
-    float fp32_threshold = 1e-28f;
-    int force_rows_per_lane = 0;
-    int emit_mode = -1;  // -1: table when the haplotype alphabet allows it; 0: always compare bytes
-    bool squash_base_quals = false;  // base qualities under 18 count as 6 (PairHMM.java:54, QualityUtils.java:57)
-    bool no_tristate_correction = false;  // PairHMM.doNotUseTristateCorrection (PairHMM.java:83-84): mismatch prior = error probability, not a third of it
-    int stream_mode = -1;  // -1: haplotype runs in table modes; 0: one haplotype per work item
-    int max_stream_haps = kMaxStreamHaps;
-    bool force_fp64 = false;
-    bool timing = false;
-    // buffers reused by the host-pointer entry points; three of them, each with a stream of its own, so that
-    // a call over many regions can plan and copy one part while the kernels of the two parts before it run
-    gatk_pairhmm_resident scratch, scratch2, scratch3;
-    hipStream_t stream2 = nullptr, stream3 = nullptr;
-    int pipeline_depth = 3;  // parts of a cut call in flight or in planning at once (2 or 3)
-    int64_t pipeline_pairs = 98304;  // pairs per part of such a call; 0: never split a call
-    int64_t pipeline_min_pairs = 12288;  // the halves of a call with less than two parts' worth of pairs are at least this large
-    PinnedBuf stage_in, stage_out;  // pinned staging shared by every upload / download on this handle
-    hipEvent_t stage_in_copied = nullptr;  // recorded behind the host-to-device copy out of stage_in
-    bool stage_in_busy = false;
-    hipStream_t stage_in_unrecorded = nullptr;  // stream of an upload whose event is still to be recorded
-    bool stage_in_record_due = false;
-    std::vector<double> likelihood_array;
-    gatk_pairhmm_stats stats{};
-    // BatchPairHMM queue: one single-read region per batchAdd
-    struct Queued {
-        std::vector<uint8_t> bases, quals, ins, del, gcp, haps;
-        std::vector<int32_t> hap_off;
-    };
-    std::vector<Queued> queue;
-    std::vector<double> queue_results;
-};
+const std::string& last_error() { return g_last_error; }
 
-namespace {
+int on_exception() noexcept {
+    try {
+        try { throw; }
+        catch (const std::bad_alloc&) { return fail(GATK_PAIRHMM_OUT_OF_MEMORY, "host memory exhausted"); }
+        catch (const std::exception& e) { return fail(GATK_PAIRHMM_DEVICE_ERROR, std::string("internal error: ") + e.what()); }
+        catch (...) { return fail(GATK_PAIRHMM_DEVICE_ERROR, "internal error: unknown exception"); }
+    } catch (...) {
+        return GATK_PAIRHMM_OUT_OF_MEMORY;  // not even the message could be stored
+    }
+}
+
+}  // namespace pairhmm_host
+
+
+namespace pairhmm_host {
 
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -482,7 +207,7 @@ int choose_group_rows_per_lane(int longest) {
     return table[longest];
 }
 
-int check_region(const gatk_pairhmm_batch& b, int k, int* read_max_out = nullptr, int* hap_max_out = nullptr) {
+int check_region(const gatk_pairhmm_batch& b, int k, int* read_max_out, int* hap_max_out) {
     const auto where = [k] { return " (region " + std::to_string(k) + ")"; };  // built only for a failure
     if (b.num_reads < 0 || b.num_haps < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("negative read or haplotype count") + where());
     if (b.num_reads == 0) return GATK_PAIRHMM_OK;  // PairHMM.java:193
@@ -637,7 +362,7 @@ int record_stage_in_event(gatk_pairhmm* h) {
 #else
 #define PLAN_CLOCK(i)
 #endif
-int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, const gatk_pairhmm_batch* regions, bool checked = false) {
+int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, const gatk_pairhmm_batch* regions, bool checked) {
     const double t_begin = now_ms();
 #ifdef PAIRHMM_CALL_CLOCKS
     double plan_clock[8] = {};
@@ -1322,21 +1047,23 @@ int digest_counters(gatk_pairhmm* h, gatk_pairhmm_resident* R, const int32_t* co
     return GATK_PAIRHMM_OK;
 }
 
-int download_into(gatk_pairhmm* h, gatk_pairhmm_resident* R, double* const* outs) {
-    if (R->total_pairs == 0) return finish_compute(h, R);
-    int with_output = 0, last = -1;
+int download_begin(gatk_pairhmm* h, gatk_pairhmm_resident* R, double* const* outs, PendingDownload& d) {
+    d = PendingDownload{};
+    d.active = true;
+    if (R->total_pairs == 0) return GATK_PAIRHMM_OK;  // end waits for the stream and digests
+    int with_output = 0;
     for (int k = 0; k < R->num_regions; ++k) {
         if (R->region_out_off[k + 1] == R->region_out_off[k]) continue;
         if (!outs || !outs[k]) {
             (void)finish_compute(h, R);
+            d.active = false;
             return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "likelihoods cannot be null");
         }
-        ++with_output; last = k;
+        ++with_output;
     }
     const size_t bytes = static_cast<size_t>(R->total_pairs) * sizeof(double);
     if (with_output == 1 && bytes > (size_t{256} << 10)) {  // a large single matrix: straight into the caller's array
-        if (int rc = finish_compute(h, R)) return rc;
-        HIP_TRY(hipMemcpy(outs[last], R->out(), bytes, hipMemcpyDeviceToHost));
+        d.direct = true;
         return GATK_PAIRHMM_OK;
     }
     // counters and likelihoods in one device-to-host copy into pinned memory, one wait, then scatter on the host
@@ -1349,41 +1076,66 @@ int download_into(gatk_pairhmm* h, gatk_pairhmm_resident* R, double* const* outs
     const bool by_kernel = down_bytes <= h->kernel_download_bytes && down_bytes <= h->stage_out.cap && down_bytes <= R->d_out.cap &&
                            static_cast<void*>(R->counters()) == R->d_out.p;
     // (not with pass timings pending: their events are read right after, and only a wait through the runtime makes them readable)
-    const bool by_signal = by_kernel && down_bytes <= h->signal_download_bytes && R->ev_pending.empty();
-    bool waited = false;
-    const uint8_t* landed = static_cast<const uint8_t*>(h->stage_out.p);
-    if (by_signal) {
+    d.by_signal = by_kernel && down_bytes <= h->signal_download_bytes && R->ev_pending.empty();
+    d.landed = static_cast<const uint8_t*>(h->stage_out.p);
+    if (d.by_signal) {
         if (!h->done_flag.p) {
             HIP_TRY(h->done_flag.ensure(64, true));
             *static_cast<volatile unsigned*>(h->done_flag.p) = 0;
         }
         HIP_TRY(h->signal_out.ensure(down_bytes, true));
-        landed = static_cast<const uint8_t*>(h->signal_out.p);
-        const unsigned seq = ++h->done_seq ? h->done_seq : ++h->done_seq;  // never 0, the flag's initial value
-        unsigned* const flag = static_cast<unsigned*>(h->done_flag.p);
-        HIP_TRY(launch_download_and_signal(R->d_out.p, h->signal_out.p, down_bytes, kCounterBytes, flag, seq, R->stream));
+        d.landed = static_cast<const uint8_t*>(h->signal_out.p);
+        d.seq = ++h->done_seq ? h->done_seq : ++h->done_seq;  // never 0, the flag's initial value
+        HIP_TRY(launch_download_and_signal(R->d_out.p, h->signal_out.p, down_bytes, kCounterBytes, static_cast<unsigned*>(h->done_flag.p), d.seq, R->stream));
         R->counters_clear = true;
+        return GATK_PAIRHMM_OK;
+    }
+    if (by_kernel) HIP_TRY(launch_download(R->d_out.p, h->stage_out.p, down_bytes, kCounterBytes, R->stream));
+    else HIP_TRY(hipMemcpyAsync(h->stage_out.p, R->d_out.p, kCounterBytes + bytes, hipMemcpyDeviceToHost, R->stream));
+    // the host waits for the copy only; the runtime's copy leaves the counters to a memset behind it
+    if (!R->ev_downloaded) HIP_TRY(hipEventCreateWithFlags(&R->ev_downloaded, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(R->ev_downloaded, R->stream));
+    if (!by_kernel) HIP_TRY(hipMemsetAsync(R->counters(), 0, kCounterBytes, R->stream));
+    R->counters_clear = true;
+    return GATK_PAIRHMM_OK;
+}
+
+bool download_ready(gatk_pairhmm* h, gatk_pairhmm_resident* R, const PendingDownload& d) {
+    if (!d.active) return true;
+    if (R->total_pairs == 0 || d.direct) return hipStreamQuery(R->stream) != hipErrorNotReady;
+    if (d.by_signal) return __atomic_load_n(static_cast<const unsigned*>(h->done_flag.p), __ATOMIC_ACQUIRE) == d.seq || hipStreamQuery(R->stream) != hipErrorNotReady;
+    return hipEventQuery(R->ev_downloaded) != hipErrorNotReady;
+}
+
+int download_end(gatk_pairhmm* h, gatk_pairhmm_resident* R, double* const* outs, PendingDownload& d) {
+    d.active = false;
+    if (R->total_pairs == 0) return finish_compute(h, R);
+    if (d.direct) {
+        if (int rc = finish_compute(h, R)) return rc;
+        int last = -1;
+        for (int k = 0; k < R->num_regions; ++k)
+            if (R->region_out_off[k + 1] != R->region_out_off[k]) last = k;
+        HIP_TRY(hipMemcpy(outs[last], R->out(), static_cast<size_t>(R->total_pairs) * sizeof(double), hipMemcpyDeviceToHost));
+        return GATK_PAIRHMM_OK;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    if (d.by_signal) {
         // A region-sized pass is over in tens of microseconds: poll for them, then leave the rest to the runtime
         // (which also reports a failed launch; the flag alone would never come).
+        const unsigned* const flag = static_cast<const unsigned*>(h->done_flag.p);
+        bool waited = false;
         const double t_poll = now_ms();
         for (unsigned spins = 0;; ++spins) {
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { waited = true; break; }
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == d.seq) { waited = true; break; }
             __builtin_ia32_pause();
             if ((spins & 1023u) == 1023u && now_ms() - t_poll > 2.0) break;
         }
         if (!waited) HIP_TRY(hipStreamSynchronize(R->stream));
     } else {
-        if (by_kernel) HIP_TRY(launch_download(R->d_out.p, h->stage_out.p, down_bytes, kCounterBytes, R->stream));
-        else HIP_TRY(hipMemcpyAsync(h->stage_out.p, R->d_out.p, kCounterBytes + bytes, hipMemcpyDeviceToHost, R->stream));
-        // the host waits for the copy only; the runtime's copy leaves the counters to a memset behind it
-        if (!R->ev_downloaded) HIP_TRY(hipEventCreateWithFlags(&R->ev_downloaded, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(R->ev_downloaded, R->stream));
-        if (!by_kernel) HIP_TRY(hipMemsetAsync(R->counters(), 0, kCounterBytes, R->stream));
-        R->counters_clear = true;
         HIP_TRY(hipEventSynchronize(R->ev_downloaded));
     }
-    if (int rc = digest_counters(h, R, reinterpret_cast<const int32_t*>(landed))) return rc;
-    const double* src = reinterpret_cast<const double*>(landed + kCounterBytes);
+    if (int rc = digest_counters(h, R, reinterpret_cast<const int32_t*>(d.landed))) return rc;
+    const double* src = reinterpret_cast<const double*>(d.landed + kCounterBytes);
     for (int k = 0; k < R->num_regions; ++k) {
         const int64_t n = R->region_out_off[k + 1] - R->region_out_off[k];
         if (n > 0) memcpy(outs[k], src + R->region_out_off[k], static_cast<size_t>(n) * sizeof(double));
@@ -1391,13 +1143,17 @@ int download_into(gatk_pairhmm* h, gatk_pairhmm_resident* R, double* const* outs
     return GATK_PAIRHMM_OK;
 }
 
+int download_into(gatk_pairhmm* h, gatk_pairhmm_resident* R, double* const* outs) {
+    PendingDownload d;
+    if (int rc = download_begin(h, R, outs, d)) return rc;
+    return download_end(h, R, outs, d);
+}
+
 int check_handle(gatk_pairhmm* h) {
     if (!h) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "PairHMM handle cannot be null");
     return GATK_PAIRHMM_OK;
 }
 
-// The resident interface, the allocation-free entry point and the stream getter work on one device: on a
-// multi-device handle they are served by the engine of the first device in the handle's list.
 gatk_pairhmm* first_engine(gatk_pairhmm* h) {
     if (h && !h->children.empty()) {
         h->stats_in_first_engine = true;
@@ -1406,7 +1162,7 @@ gatk_pairhmm* first_engine(gatk_pairhmm* h) {
     return h;
 }
 
-}  // namespace
+}  // namespace pairhmm_host
 
 // =================================================================================================
 // C ABI
@@ -1485,13 +1241,15 @@ int gatk_pairhmm_initialize(gatk_pairhmm* h, int32_t read_max_length, int32_t ha
 
 static int compute_regions_multi(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions, double* const* likelihoods);
 
+}  // extern "C"
+
 // compute_regions on a single-device handle.  checked: the caller has run check_region on every region already.
 #ifdef PAIRHMM_CALL_CLOCKS
 #define CALL_CLOCK(label) std::fprintf(stderr, "  %8.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - call_t0).count(), label)
 #else
 #define CALL_CLOCK(label)
 #endif
-static int compute_regions_single(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
+int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
                                   double* const* likelihoods, bool checked) {
 #ifdef PAIRHMM_CALL_CLOCKS
     const auto call_t0 = std::chrono::steady_clock::now();
@@ -1623,6 +1381,8 @@ static int compute_regions_single(gatk_pairhmm* h, int32_t num_regions, const ga
     h->stats = total;
     return GATK_PAIRHMM_OK;
 }
+
+extern "C" {
 
 int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
                                  double* const* likelihoods) try {
@@ -1819,6 +1579,7 @@ Combiner* combiner_for(int device, bool squash) {
 // be under way then: a call needs a handle); the next combined call creates them again.
 void release_shared_engines_if_last() {
     if (g_live_handles.fetch_sub(1) != 1) return;
+    release_dispatch_engines();
     std::lock_guard<std::mutex> lock(g_combiners_mutex);
     for (auto& kv : g_combiners) {
         Combiner* c = kv.second;
@@ -1905,14 +1666,8 @@ int compute_combined(int device, bool squash, const gatk_pairhmm_batch* batch, d
         std::string create_error;
         lock.unlock();
         if (!c->engine[e]) {  // only the thread that holds busy[e] touches engine[e]
-            create_rc = gatk_pairhmm_create(device, &c->engine[e]);
-            if (create_rc == GATK_PAIRHMM_OK) {
-                c->engine[e]->squash_base_quals = squash;
-                c->engine[e]->is_shared_engine = true;  // not a caller's handle
-                c->engine[e]->counted = false;
-                g_live_handles.fetch_sub(1);
-            }
-            else create_error = g_last_error;
+            create_rc = create_shared_engine(device, squash, &c->engine[e]);
+            if (create_rc != GATK_PAIRHMM_OK) create_error = g_last_error;
         }
 #ifdef PAIRHMM_CALL_CLOCKS
         const auto dbg_t0 = std::chrono::steady_clock::now();
@@ -1945,28 +1700,30 @@ int gatk_pairhmm_compute_likelihoods(gatk_pairhmm* h, const gatk_pairhmm_batch* 
     const int64_t n = static_cast<int64_t>(batch->num_reads) * std::max(batch->num_haps, 0);
     if (n > 0 && !likelihoods) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "likelihoods cannot be null");
     double* outs[1] = {likelihoods};
-    // combined: a call that cannot fill the device by itself, on a handle whose other options are the defaults
-    const bool plain = h->fp32_threshold == 1e-28f && h->force_rows_per_lane == 0 && !h->force_fp64 && h->emit_mode == -1 &&
-                       h->stream_mode == -1 && !h->timing && !h->no_tristate_correction;
-    bool combined = false;
-    if (h->combine_calls && h->children.empty() && plain && n < 4 * static_cast<int64_t>(h->wave_slots)) {
-        // With few callers on the device at this moment a call is better off alone on its own handle (4 threads: 16.5 us
-        // per region alone, 21 through the shared engines, of which there are three); from the fifth caller under way
-        // the calls share passes.
-        std::atomic<int>& under_way = g_small_calls_under_way[h->device & 63];
-        const int before_me = under_way.fetch_add(1, std::memory_order_acq_rel);
-        struct Leave { std::atomic<int>& n; ~Leave() { n.fetch_sub(1, std::memory_order_acq_rel); } } leave{under_way};
-        if (before_me >= h->combine_from_callers) {
-            int read_max = 0, hap_max = 0;
-            if (int rc = check_region(*batch, 0, &read_max, &hap_max)) return rc;
-            if (int rc = compute_combined(h->device, h->squash_base_quals, batch, likelihoods)) return rc;
-            h->stats = gatk_pairhmm_stats{};
-            h->stats.pairs = n;
-            note_call_maxima(h, *batch, read_max, hap_max);
-            combined = true;
-        } else if (int rc = gatk_pairhmm_compute_regions(h, 1, batch, outs)) return rc;
+    // a sample of the region sent ahead with gatk_pairhmm_initialize_region: its likelihoods are there already, or on their way
+    bool served = false;
+    if (h->region_ticket != 0)
+        if (int rc = serve_from_region(h, batch, likelihoods, &served)) return rc;
+    if (served) {
+        h->stats = gatk_pairhmm_stats{};
+        h->stats.pairs = n;
+    } else if (h->combine_calls != 0 && h->children.empty() && has_default_options(h) && n < 4 * static_cast<int64_t>(h->wave_slots)) {
+        // a call that cannot fill the device by itself, on a handle whose other options are the defaults: it shares
+        // the device's dispatcher with the region-sized calls other threads make at the same time
+        int read_max = 0, hap_max = 0;
+        if (int rc = check_region(*batch, 0, &read_max, &hap_max)) return rc;
+        if (h->combine_calls == 2) {  // the blocking leader / follower combiner
+            std::atomic<int>& under_way = g_small_calls_under_way[h->device & 63];
+            const int before_me = under_way.fetch_add(1, std::memory_order_acq_rel);
+            struct Leave { std::atomic<int>& n; ~Leave() { n.fetch_sub(1, std::memory_order_acq_rel); } } leave{under_way};
+            if (before_me >= h->combine_from_callers) {
+                if (int rc = compute_combined(h->device, h->squash_base_quals, batch, likelihoods)) return rc;
+            } else if (int rc = gatk_pairhmm_compute_regions(h, 1, batch, outs)) return rc;
+        } else if (int rc = compute_shared(h, batch, likelihoods)) return rc;
+        h->stats = gatk_pairhmm_stats{};
+        h->stats.pairs = n;
+        note_call_maxima(h, *batch, read_max, hap_max);
     } else if (int rc = gatk_pairhmm_compute_regions(h, 1, batch, outs)) return rc;
-    (void)combined;
     h->likelihood_array.assign(likelihoods, likelihoods + n);  // mLikelihoodArray, PairHMM.java:206,225
     return GATK_PAIRHMM_OK;
 } catch (...) { return on_exception(); }
@@ -2090,11 +1847,13 @@ int gatk_pairhmm_get_likelihood_array(gatk_pairhmm* h, const double** array, int
 int gatk_pairhmm_finalize_region(gatk_pairhmm* h) try {
     if (int rc = check_handle(h)) return rc;
     h->queue.clear();
+    drop_region(h);
     return GATK_PAIRHMM_OK;
 } catch (...) { return on_exception(); }
 
 int gatk_pairhmm_close(gatk_pairhmm* h) try {
     if (!h) return GATK_PAIRHMM_OK;
+    drop_tickets(h);  // nothing may write into this handle's requests any more
     if (!h->children.empty() || !h->workers.empty()) {  // a multi-device handle owns engines and threads only
         for (auto& w : h->workers) w->shutdown();
         for (gatk_pairhmm* c : h->children) gatk_pairhmm_close(c);
@@ -2127,6 +1886,10 @@ int gatk_pairhmm_get_stats(gatk_pairhmm* h, gatk_pairhmm_stats* out) try {
     if (int rc = check_handle(h)) return rc;
     if (!out) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "out cannot be null");
     *out = (!h->children.empty() && h->stats_in_first_engine) ? h->children[0]->stats : h->stats;
+    const gatk_pairhmm* e = h->children.empty() ? h : h->children[0];
+    dispatch_counts(e->device, e->squash_base_quals, &out->shared_passes, &out->shared_requests);
+    out->region_hits = h->region_hits;
+    out->region_misses = h->region_misses;
     return GATK_PAIRHMM_OK;
 } catch (...) { return on_exception(); }
 
@@ -2150,7 +1913,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) try
     else if (n == "pipeline_ramp") h->pipeline_ramp = value != 0;
     else if (n == "pipeline_depth") h->pipeline_depth = value >= 3 ? 3 : 2;
     else if (n == "pipeline_min_pairs") h->pipeline_min_pairs = std::max<int64_t>(1, static_cast<int64_t>(value));
-    else if (n == "combine_calls") h->combine_calls = value != 0;
+    else if (n == "combine_calls") h->combine_calls = static_cast<int>(value);
     else if (n == "combine_from_callers") h->combine_from_callers = std::max(0, static_cast<int>(value));
     else if (n == "per_group_factor") h->per_group_factor = std::max<int64_t>(1, static_cast<int64_t>(value));
     else if (n == "kernel_download_bytes") h->kernel_download_bytes = static_cast<size_t>(std::max(0.0, value));
@@ -2343,6 +2106,17 @@ int gatk_pairhmm_resident_device_output(gatk_pairhmm_resident* r, void** device_
 } catch (...) { return on_exception(); }
 
 }  // extern "C"
+
+// An engine of a device's dispatcher (or of the call combiner): a single-device handle that is nobody's own.
+int pairhmm_host::create_shared_engine(int device, bool squash, gatk_pairhmm** out) {
+    const int rc = gatk_pairhmm_create(device, out);
+    if (rc != GATK_PAIRHMM_OK) return rc;
+    (*out)->squash_base_quals = squash;
+    (*out)->is_shared_engine = true;  // not a caller's handle
+    (*out)->counted = false;
+    g_live_handles.fetch_sub(1);
+    return GATK_PAIRHMM_OK;
+}
 
 // =================================================================================================
 // The entry point that allocates nothing

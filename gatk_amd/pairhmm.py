@@ -59,7 +59,10 @@ class CStats(C.Structure):
                 ("rerun_pairs", C.c_int64), ("fp32_kernel_ms", C.c_double), ("fp64_kernel_ms", C.c_double),
                 ("host_plan_ms", C.c_double), ("host_upload_ms", C.c_double), ("aux_kernel_ms", C.c_double),
                 ("timed_passes", C.c_int64), ("main_rows_per_lane", C.c_int32), ("main_emit_mode", C.c_int32),
-                ("main_stream_pass", C.c_int32), ("main_fp64", C.c_int32)]
+                ("main_stream_pass", C.c_int32), ("main_fp64", C.c_int32),
+                ("lane_rows_allocated", C.c_int64), ("lane_rows_used", C.c_int64),
+                ("shared_passes", C.c_int64), ("shared_requests", C.c_int64),
+                ("region_hits", C.c_int64), ("region_misses", C.c_int64)]
 
 
 # every symbol include/gatk_pairhmm.h declares
@@ -73,6 +76,7 @@ EXPORTS = [
     "gatk_pairhmm_resident_free", "gatk_pairhmm_get_stream", "gatk_pairhmm_resident_device_output",
     "gatk_pairhmm_wait_resident", "gatk_pairhmm_normalize_resident", "gatk_pairhmm_poorly_modeled_resident",
     "gatk_pairhmm_marginalize_resident", "gatk_pairhmm_compute_likelihoods_noalloc", "gatk_pairhmm_create_multi",
+    "gatk_pairhmm_initialize_region", "gatk_pairhmm_submit", "gatk_pairhmm_fetch",
 ]
 
 _lib = None
@@ -117,6 +121,9 @@ def load_library():
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
         L.gatk_pairhmm_compute_likelihoods_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CBatch), C.c_int32, C.c_int32,
                                                                C.c_void_p, C.c_void_p]
+        L.gatk_pairhmm_initialize_region.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CBatch), C.c_int32, C.c_int32]
+        L.gatk_pairhmm_submit.argtypes = [C.c_void_p, C.c_int32, C.POINTER(CBatch), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.gatk_pairhmm_fetch.argtypes = [C.c_void_p, C.c_int64]
         L.gatk_pairhmm_device_count.argtypes = [C.POINTER(C.c_int32)]
         L.gatk_pairhmm_set_number_of_threads.argtypes = [C.c_int32]
         _lib = L
@@ -268,6 +275,20 @@ class PreparedRegions:
         return self.outs
 
 
+class Ticket:
+    """An outstanding gatk_pairhmm_submit call; the output arrays stay alive with it."""
+
+    def __init__(self, hmm, ticket, outs):
+        self.hmm, self.ticket, self.outs = hmm, ticket, outs
+
+    def fetch(self):
+        t, self.ticket = self.ticket, None
+        if t is None:
+            raise IllegalStateException("the ticket has been fetched already")
+        _check(self.hmm._lib.gatk_pairhmm_fetch(self.hmm._h, t))
+        return self.outs
+
+
 class HipLoglessPairHMM:
     """PairHMM (PairHMM.java:46) implemented by the gfx950 engine."""
 
@@ -286,6 +307,33 @@ class HipLoglessPairHMM:
     # -- PairHMM.java:104 --
     def initialize(self, readMaxLength, haplotypeMaxLength):
         _check(self._lib.gatk_pairhmm_initialize(self._h, readMaxLength, haplotypeMaxLength))
+
+    # -- PairHMM.java:137 --
+    def initializeRegion(self, haplotypes, perSampleReadList, readMaxLength, haplotypeMaxLength):
+        """PairHMM.initialize(haplotypes, perSampleReadList, readMaxLength, haplotypeMaxLength): sends every sample's
+        reads (perSampleReadList: dict sample -> list of (bases, quals, insQuals|None, delQuals|None)) and the region's
+        haplotypes to the device in one pass and returns without waiting; the computeLikelihoods calls that follow
+        find their likelihoods there."""
+        batches = [pack([(r[0], r[1], r[2], r[3], None) for r in reads], haplotypes) for reads in perSampleReadList.values()]
+        for b in batches:
+            b.gcp = None  # the GCP map only comes with computeLikelihoods (PairHMM.java:190-192)
+        self.initialize_region_batches(batches, readMaxLength, haplotypeMaxLength)
+
+    def initialize_region_batches(self, batches, readMaxLength, haplotypeMaxLength):
+        keep = []
+        cbs = (CBatch * max(1, len(batches)))(*[to_cbatch(b, keep) for b in batches])
+        _check(self._lib.gatk_pairhmm_initialize_region(self._h, len(batches), cbs, readMaxLength, haplotypeMaxLength))
+
+    # -- submit / fetch: compute_regions in two halves --
+    def submit(self, regions):
+        """gatk_pairhmm_submit: returns a ticket object at once; ticket.fetch() returns the per-region arrays."""
+        keep = []
+        cbs = (CBatch * max(1, len(regions)))(*[to_cbatch(b, keep) for b in regions])
+        outs = [np.full((b.num_reads, b.num_haps), np.nan, dtype=np.float64) for b in regions]
+        arr = (C.c_void_p * max(1, len(regions)))(*[o.ctypes.data if o.size else None for o in outs])
+        t = C.c_int64()
+        _check(self._lib.gatk_pairhmm_submit(self._h, len(regions), cbs, arr, C.byref(t)))
+        return Ticket(self, t.value, outs)
 
     # -- PairHMM.java:190 --
     def computeLikelihoods(self, likelihoods: ReadLikelihoodsMatrix, processedReads, gcp=None):

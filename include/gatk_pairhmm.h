@@ -87,6 +87,18 @@ typedef struct gatk_pairhmm_stats {
     int32_t main_emit_mode;      /* 0 compares bytes, 1 same with haplotype N, 2 emission table A/C/G/T, 3 table with N */
     int32_t main_stream_pass;    /* 1: the fp32 stream pass (haplotype runs), 0: the one-haplotype pass */
     int32_t main_fp64;           /* 1: everything was scored in fp64 (force_fp64) */
+    /* Read rows the fp32 forward launches of the call gave to lanes (64 lanes x rows per lane, per wave-group and
+     * haplotype) and the rows among them that hold a row of a read's matrix: their ratio is how full the lanes ran. */
+    int64_t lane_rows_allocated;
+    int64_t lane_rows_used;
+    /* Since the process started, on this handle's device: device passes run for calls that share the device's
+     * dispatcher (submit / fetch, regions sent ahead, "combine_calls") and the calls those passes carried. */
+    int64_t shared_passes;
+    int64_t shared_requests;
+    /* On this handle: computeLikelihoods calls answered from a region sent ahead with initialize_region, and calls
+     * made while such a region was held that matched none of its samples. */
+    int64_t region_hits;
+    int64_t region_misses;
 } gatk_pairhmm_stats;
 
 /* Constructor of a PairHMM instance on GPU `device` (replaces the JNI library's one-time
@@ -115,6 +127,38 @@ int gatk_pairhmm_create_multi(const int32_t* devices, int32_t num_devices, gatk_
  * haplotype exceeds the current maxima re-initialises the instance with that call's two maxima, as
  * PairHMM.java:198-201 does (so the other maximum may shrink; compute_pair checks against them). */
 int gatk_pairhmm_initialize(gatk_pairhmm* h, int32_t read_max_length, int32_t haplotype_max_length);
+
+/* PairHMM.initialize(List<Haplotype> haplotypes, Map<String, List<GATKSAMRecord>> perSampleReadList, int readMaxLength,
+ * int haplotypeMaxLength), PairHMM.java:129-139: "used by the JNI implementations to transfer all data once to the
+ * native code".  per_sample[s] holds sample s's reads against the region's haplotypes (every entry carries the
+ * haplotypes; gcp is normally NULL here, the GCP map only arrives with computeLikelihoods, PairHMM.java:190-192, and
+ * NULL stands for the constant 10 HaplotypeCaller passes).  The call does what initialize(int, int) does, copies the
+ * bytes, starts ONE device pass over all samples and returns without waiting for it.  A later
+ * gatk_pairhmm_compute_likelihoods on this handle whose batch is byte for byte one of these samples (lengths, bases,
+ * qualities, haplotypes; an array left out on one side equals an array of its default on the other) waits for that
+ * pass and copies the sample's likelihoods out; any other batch (another sample, a GCP that is not the default) is
+ * scored the ordinary way, and so is every sample when the pass reported an input error, so that the reference's
+ * exception comes from the computeLikelihoods call whose reads raise it.  Shape errors (PairHMM.java:105-106, null or
+ * over-long arrays) are returned here.  The region is forgotten at gatk_pairhmm_finalize_region, at the next
+ * initialize_region and at close. */
+int gatk_pairhmm_initialize_region(gatk_pairhmm* h, int32_t num_samples, const gatk_pairhmm_batch* per_sample,
+                                   int32_t read_max_length, int32_t haplotype_max_length);
+
+/* gatk_pairhmm_compute_regions in two halves, for a host thread that keeps region n + 1 on the device while it consumes
+ * region n (one map thread of nanoScheduler/NanoScheduler.java:112 with two PairHMM.computeLikelihoods calls,
+ * PairHMM.java:190-236, in flight).  submit checks the shapes (their errors are returned here), copies every input
+ * byte (the caller's input arrays are free again when it returns), hands the regions to the device's dispatcher and
+ * returns a ticket without waiting.  fetch(ticket) returns when likelihoods[k] (which must stay valid until then;
+ * another thread of the process may be the one that writes them) hold the results, with the code of the reference's
+ * exception if the data raised one (negative gap qualities, base quality 255), and forgets the ticket.  Any number
+ * of tickets may be outstanding on a handle, fetched in any order; close drops the ones never fetched.
+ * The dispatcher is per device and shared by all handles: requests of several threads that are waiting when an
+ * engine falls free go through ONE device pass, so region-sized calls fill the device the better the more callers
+ * there are.  A call of more than "pipeline_pairs" pairs, or on a handle with non-default result options, is scored
+ * before submit returns.  On a multi-device handle the requests go to the devices in turn. */
+int gatk_pairhmm_submit(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions, double* const* likelihoods,
+                        int64_t* ticket);
+int gatk_pairhmm_fetch(gatk_pairhmm* h, int64_t ticket);
 
 /* PairHMM.computeLikelihoods, PairHMM.java:190-236 (upstream JNI: jniComputeLikelihoods).
  * likelihoods[r * num_haps + a] = log10 P(read r | haplotype a): the read-major order of
@@ -155,7 +199,8 @@ int gatk_pairhmm_batch_get_result(gatk_pairhmm* h, const double** results, int64
  * compute_likelihoods call; handle-owned. */
 int gatk_pairhmm_get_likelihood_array(gatk_pairhmm* h, const double** array, int64_t* count);
 
-/* PairHMM.finalizeRegion(), PairHMM.java:124: end of a region; drops per-region state. */
+/* PairHMM.finalizeRegion(), PairHMM.java:121-127: end of a region; drops per-region state (the BatchPairHMM queue, the
+ * region sent ahead with gatk_pairhmm_initialize_region and its results). */
 int gatk_pairhmm_finalize_region(gatk_pairhmm* h);
 
 /* PairHMM.close(), PairHMM.java:364 (upstream JNI: jniClose): frees the handle and its

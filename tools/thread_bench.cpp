@@ -1,7 +1,10 @@
 // Region-at-a-time calls from T host threads, one handle per thread (how the reference's map threads would
 // drive a PairHMM, nanoScheduler/NanoScheduler.java:112 and pairhmm/PairHMM.java:297), with and without the
 // handle option "combine_calls".  Synthetic HaplotypeCaller-sized regions: 30-100 reads of 121-151 bases,
-// 2-16 haplotypes of 250-500 bases.  usage: thread_bench REGIONS THREADS COMBINE(0|1) [OPTION VALUE ...]
+// 2-16 haplotypes of 250-500 bases.  usage: thread_bench REGIONS THREADS COMBINE [OPTION VALUE ...]
+// COMBINE: 0 = blocking calls, each on its own handle; 1 = blocking calls that share the device's dispatcher
+// ("combine_calls"); 2 = the same through the blocking combiner; -D = gatk_pairhmm_submit / gatk_pairhmm_fetch with D
+// regions in flight per thread.
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -61,7 +64,7 @@ int main(int argc, char** argv) {
     std::vector<gatk_pairhmm*> handles(threads, nullptr);
     for (auto& h : handles) {
         if (gatk_pairhmm_create(0, &h)) { std::printf("%s\n", gatk_pairhmm_last_error()); return 1; }
-        gatk_pairhmm_set_option(h, "combine_calls", combine);
+        gatk_pairhmm_set_option(h, "combine_calls", combine > 0 ? combine : 0);
         for (int a = 4; a + 1 < argc; a += 2) gatk_pairhmm_set_option(h, argv[a], std::atof(argv[a + 1]));  // further engine options: NAME VALUE ...
     }
     double best = 1e30;
@@ -71,8 +74,26 @@ int main(int argc, char** argv) {
         std::vector<std::thread> pool;
         for (int t = 0; t < threads; ++t)
             pool.emplace_back([&, t] {
-                for (int k; (k = next.fetch_add(1)) < num_regions;)
-                    if (gatk_pairhmm_compute_likelihoods(handles[t], &regions[k].c, regions[k].out.data())) failed.store(1);
+                if (combine >= 0) {
+                    for (int k; (k = next.fetch_add(1)) < num_regions;)
+                        if (gatk_pairhmm_compute_likelihoods(handles[t], &regions[k].c, regions[k].out.data())) failed.store(1);
+                    return;
+                }
+                // submit / fetch: -combine regions in flight, the oldest fetched before the next goes out
+                std::vector<int64_t> ring(static_cast<size_t>(-combine), 0);
+                size_t head = 0, live = 0;
+                for (int k; (k = next.fetch_add(1)) < num_regions;) {
+                    if (live == ring.size()) {
+                        if (gatk_pairhmm_fetch(handles[t], ring[head])) failed.store(1);
+                        head = (head + 1) % ring.size(); --live;
+                    }
+                    double* out = regions[k].out.data();
+                    int64_t ticket = 0;
+                    if (gatk_pairhmm_submit(handles[t], 1, &regions[k].c, &out, &ticket)) { failed.store(1); continue; }
+                    ring[(head + live) % ring.size()] = ticket; ++live;
+                }
+                for (; live > 0; --live, head = (head + 1) % ring.size())
+                    if (gatk_pairhmm_fetch(handles[t], ring[head])) failed.store(1);
             });
         for (auto& th : pool) th.join();
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -81,6 +102,9 @@ int main(int argc, char** argv) {
     }
     double sum = 0;
     for (const Region& r : regions) for (double v : r.out) sum += v;
+    gatk_pairhmm_stats st{};
+    gatk_pairhmm_get_stats(handles[0], &st);
+    if (st.shared_passes) std::printf("(%.2f requests per shared pass) ", double(st.shared_requests) / double(st.shared_passes));
     std::printf("regions %d threads %d combine_calls %d: %.2f ms, %.1f us per region, %.0f GCUPS (checksum %.6f)\n", num_regions, threads, combine,
                 best * 1e3, best * 1e6 / num_regions, cells / best / 1e9, sum);
     for (auto h : handles) gatk_pairhmm_close(h);
