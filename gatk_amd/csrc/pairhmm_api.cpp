@@ -39,8 +39,9 @@ namespace {
 
 thread_local std::string g_last_error;
 std::atomic<int> g_num_threads{1};
-std::atomic<int> g_live_handles{0};  // callers' single-device handles (the combiner's shared engines are not counted)
+std::atomic<int> g_live_handles{0};  // callers' single-device handles (the dispatchers' shared engines are not counted)
 void release_shared_engines_if_last();
+int g_fail_share_for_test = -1;  // gatk_pairhmm_debug_fail_share: the multi-device share of this engine throws once it is done
 // compute_regions calls under way per device (all handles): a call that has the device to itself overlaps
 // its own halves; one that shares it is overlapped with the calls of the other handles already
 std::atomic<int> g_region_calls[64];  // indexed by device & 63: devices 64 apart would share a count, which only costs overlap
@@ -1498,15 +1499,29 @@ static int compute_regions_multi(gatk_pairhmm* h, int32_t num_regions, const gat
         std::sort(mine[d].begin(), mine[d].end());  // input order within a device: neighbouring read ranges stay neighbours
         for (int i : mine[d]) { shares[d].batches.push_back(pieces[i].b); shares[d].outs.push_back(pieces[i].out); }
     }
-    auto run = [&](int d) {
+    // Nothing may leave a share's job as an exception: on a worker thread it would end the process, and on this
+    // thread it would unwind `shares` from under the workers that are still scoring into it.
+    auto run = [&](int d) noexcept {
         Share& sh = shares[d];
-        if (sh.batches.empty()) { h->children[d]->stats = gatk_pairhmm_stats{}; return; }
-        sh.rc = compute_regions_single(h->children[d], static_cast<int32_t>(sh.batches.size()), sh.batches.data(), sh.outs.data(), true);
-        if (sh.rc != GATK_PAIRHMM_OK) sh.error = g_last_error;  // this thread's message
+        try {
+            if (sh.batches.empty()) { h->children[d]->stats = gatk_pairhmm_stats{}; return; }
+            sh.rc = compute_regions_single(h->children[d], static_cast<int32_t>(sh.batches.size()), sh.batches.data(), sh.outs.data(), true);
+            if (g_fail_share_for_test == d) throw std::runtime_error("injected failure");
+        } catch (...) {
+            sh.rc = on_exception();
+        }
+        if (sh.rc != GATK_PAIRHMM_OK) {
+            try { sh.error = g_last_error; } catch (...) {}  // this thread's message
+        }
     };
-    for (int d = 1; d < n_dev; ++d) h->workers[d - 1]->submit([&run, d] { run(d); });
-    run(0);
-    for (int d = 1; d < n_dev; ++d) h->workers[d - 1]->wait();
+    {
+        struct WaitForWorkers {  // every worker is done before `run` and `shares` go, whatever happens on this thread
+            gatk_pairhmm* h; int started = 0;
+            ~WaitForWorkers() { for (int k = 0; k < started; ++k) h->workers[k]->wait(); }
+        } guard{h};
+        for (int d = 1; d < n_dev; ++d) { h->workers[d - 1]->submit([&run, d] { run(d); }); guard.started = d; }
+        run(0);
+    }
     gatk_pairhmm_stats total{};
     for (int d = 0; d < n_dev; ++d) {  // counts add up; times are the slowest device's
         const gatk_pairhmm_stats& st = h->children[d]->stats;
@@ -1530,165 +1545,11 @@ static int compute_regions_multi(gatk_pairhmm* h, int32_t num_regions, const gat
 
 namespace {
 
-// Region-sized calls from several threads, each on its own handle (the reference's one PairHMM per map
-// thread, PairHMM.java:297), do not fill the device one at a time and do not overlap well either.  With the
-// handle option "combine_calls" such calls meet here: whichever caller finds an engine free takes every
-// request that is waiting on the device, its own included, through one gatk_pairhmm_compute_regions pass on
-// that engine and hands the results out; callers that arrive meanwhile wait for the next pass.  Three engines
-// per device, so that passes are planned and fetched while another runs.  They are released when the last caller's
-// handle closes.
-struct Combiner {
-    struct Request {
-        const gatk_pairhmm_batch* batch;
-        double* out;
-        int rc = GATK_PAIRHMM_OK;
-        std::string error;
-        bool taken = false, done = false;
-    };
-    static constexpr int kEngines = 3;
-    static constexpr int kLingerMicroseconds = 10;  // a leader that finds fewer than kLingerBelow requests waits this long for more,
-    static constexpr size_t kLingerBelow = 8;       // while another engine keeps the device busy
-    static constexpr size_t kMaxRequestsPerPass = 64;
-    static constexpr int kSpinMicroseconds = 250;   // how long a waiting caller spins for the end of a pass before it sleeps,
-    static constexpr int kMaxSpinners = 12;         // and how many callers do so at once
-    std::mutex m;
-    std::condition_variable cv;
-    std::deque<Request*> pending;
-    gatk_pairhmm* engine[kEngines] = {};
-    bool busy[kEngines] = {};
-    int spinners = 0;  // callers spinning for the end of a pass (under the mutex)
-    std::atomic<uint64_t> passes_ended{0};  // changed under the mutex; waiting callers spin on it before they sleep
-#ifdef PAIRHMM_CALL_CLOCKS
-    uint64_t dbg_passes = 0, dbg_requests = 0;
-    double dbg_run_us = 0, dbg_size_hist[9] = {};
-#endif
-};
-
-std::mutex g_combiners_mutex;
-std::map<int, Combiner*> g_combiners;
-
-// One combiner per device and per value of the one result-changing option it supports (squash_base_quals).
-Combiner* combiner_for(int device, bool squash) {
-    std::lock_guard<std::mutex> lock(g_combiners_mutex);
-    Combiner*& c = g_combiners[device * 2 + (squash ? 1 : 0)];
-    if (!c) c = new Combiner();
-    return c;
-}
-
-// The shared engines and their device buffers go when the last caller's handle on the process closes (no call can
-// be under way then: a call needs a handle); the next combined call creates them again.
+// The shared engines of the devices' dispatchers and their device buffers go when the last caller's handle of the
+// process closes (no call can be under way then: a call needs a handle); the next shared call creates them again.
 void release_shared_engines_if_last() {
     if (g_live_handles.fetch_sub(1) != 1) return;
     release_dispatch_engines();
-    std::lock_guard<std::mutex> lock(g_combiners_mutex);
-    for (auto& kv : g_combiners) {
-        Combiner* c = kv.second;
-        std::lock_guard<std::mutex> inner(c->m);
-#ifdef PAIRHMM_CALL_CLOCKS
-        if (c->dbg_passes) {
-            std::fprintf(stderr, "combiner: %llu passes, %.2f requests per pass, %.1f us per pass in the leader; passes by size/2:", (unsigned long long)c->dbg_passes,
-                         double(c->dbg_requests) / c->dbg_passes, c->dbg_run_us / c->dbg_passes);
-            for (double v : c->dbg_size_hist) std::fprintf(stderr, " %.0f", v);
-            std::fprintf(stderr, "\n");
-        }
-#endif
-        for (int e = 0; e < Combiner::kEngines; ++e)
-            if (c->engine[e] && !c->busy[e]) {
-                gatk_pairhmm_close(c->engine[e]);
-                c->engine[e] = nullptr;
-            }
-    }
-}
-
-// One pass over the requests a leader took.  A failing pass is repeated request by request so that the
-// reference's exception reaches the caller whose batch raised it, and only that caller.
-void run_combined(gatk_pairhmm* engine, const std::vector<Combiner::Request*>& reqs) {
-    std::vector<gatk_pairhmm_batch> batches;
-    std::vector<double*> outs;
-    for (const Combiner::Request* r : reqs) { batches.push_back(*r->batch); outs.push_back(r->out); }
-    if (gatk_pairhmm_compute_regions(engine, static_cast<int32_t>(reqs.size()), batches.data(), outs.data()) == GATK_PAIRHMM_OK) return;
-    for (size_t k = 0; k < reqs.size(); ++k) {
-        reqs[k]->rc = gatk_pairhmm_compute_regions(engine, 1, &batches[k], &outs[k]);
-        if (reqs[k]->rc != GATK_PAIRHMM_OK) reqs[k]->error = g_last_error;
-    }
-}
-
-std::atomic<int> g_small_calls_under_way[64];  // per device (index & 63): compute_likelihoods calls of combining handles in progress
-
-int compute_combined(int device, bool squash, const gatk_pairhmm_batch* batch, double* out) {
-    Combiner* c = combiner_for(device, squash);
-    Combiner::Request mine{batch, out};
-    std::unique_lock<std::mutex> lock(c->m);
-    c->pending.push_back(&mine);
-    while (!mine.done) {
-        int e = -1;
-        if (!mine.taken)
-            for (int k = 0; k < Combiner::kEngines && e < 0; ++k)
-                if (!c->busy[k]) e = k;
-        if (e < 0) {
-            // A pass takes about a hundred microseconds and a sleeping thread tens of microseconds to wake up:
-            // wait for the end of a pass by spinning first, and sleep only when that takes long.
-            const uint64_t seen = c->passes_ended.load(std::memory_order_acquire);
-            const bool spin = c->spinners < Combiner::kMaxSpinners;  // the rest sleep: spinning callers must not take every core
-            if (spin) ++c->spinners;
-            lock.unlock();
-            if (spin) {
-                const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(Combiner::kSpinMicroseconds);
-                for (int k = 0; c->passes_ended.load(std::memory_order_acquire) == seen; ++k) {
-                    _mm_pause();
-                    if ((k & 63) == 63 && std::chrono::steady_clock::now() >= spin_until) break;
-                }
-            }
-            lock.lock();
-            if (spin) --c->spinners;
-            if (c->passes_ended.load(std::memory_order_acquire) == seen) c->cv.wait(lock);  // the counter changes under this mutex
-            continue;
-        }
-        // lead a pass on engine e
-        c->busy[e] = true;
-        {   // a larger pass costs the device much less per region: give the other callers a moment to arrive
-            bool other_busy = false;
-            for (int k = 0; k < Combiner::kEngines; ++k) other_busy |= k != e && c->busy[k];
-            if (other_busy && c->pending.size() < Combiner::kLingerBelow) {
-                lock.unlock();
-                const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(Combiner::kLingerMicroseconds);
-                while (std::chrono::steady_clock::now() < until) _mm_pause();
-                lock.lock();
-            }
-        }
-        std::vector<Combiner::Request*> reqs;
-        while (!c->pending.empty() && reqs.size() < Combiner::kMaxRequestsPerPass) {
-            reqs.push_back(c->pending.front());
-            c->pending.pop_front();
-            reqs.back()->taken = true;
-        }
-        int create_rc = GATK_PAIRHMM_OK;
-        std::string create_error;
-        lock.unlock();
-        if (!c->engine[e]) {  // only the thread that holds busy[e] touches engine[e]
-            create_rc = create_shared_engine(device, squash, &c->engine[e]);
-            if (create_rc != GATK_PAIRHMM_OK) create_error = g_last_error;
-        }
-#ifdef PAIRHMM_CALL_CLOCKS
-        const auto dbg_t0 = std::chrono::steady_clock::now();
-#endif
-        if (create_rc == GATK_PAIRHMM_OK) run_combined(c->engine[e], reqs);
-        lock.lock();
-#ifdef PAIRHMM_CALL_CLOCKS
-        c->dbg_run_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count();
-        ++c->dbg_passes; c->dbg_requests += reqs.size();
-        c->dbg_size_hist[std::min<size_t>(reqs.size(), 16) / 2] += 1;
-#endif
-        for (Combiner::Request* r : reqs) {
-            if (create_rc != GATK_PAIRHMM_OK) { r->rc = create_rc; r->error = create_error; }
-            r->done = true;
-        }
-        c->busy[e] = false;
-        c->passes_ended.fetch_add(1, std::memory_order_release);
-        c->cv.notify_all();
-    }
-    lock.unlock();
-    return mine.rc == GATK_PAIRHMM_OK ? GATK_PAIRHMM_OK : fail(mine.rc, mine.error);
 }
 
 }  // namespace
@@ -1707,19 +1568,12 @@ int gatk_pairhmm_compute_likelihoods(gatk_pairhmm* h, const gatk_pairhmm_batch* 
     if (served) {
         h->stats = gatk_pairhmm_stats{};
         h->stats.pairs = n;
-    } else if (h->combine_calls != 0 && h->children.empty() && has_default_options(h) && n < 4 * static_cast<int64_t>(h->wave_slots)) {
+    } else if (h->combine_calls && h->children.empty() && has_default_options(h) && n < 4 * static_cast<int64_t>(h->wave_slots)) {
         // a call that cannot fill the device by itself, on a handle whose other options are the defaults: it shares
         // the device's dispatcher with the region-sized calls other threads make at the same time
         int read_max = 0, hap_max = 0;
         if (int rc = check_region(*batch, 0, &read_max, &hap_max)) return rc;
-        if (h->combine_calls == 2) {  // the blocking leader / follower combiner
-            std::atomic<int>& under_way = g_small_calls_under_way[h->device & 63];
-            const int before_me = under_way.fetch_add(1, std::memory_order_acq_rel);
-            struct Leave { std::atomic<int>& n; ~Leave() { n.fetch_sub(1, std::memory_order_acq_rel); } } leave{under_way};
-            if (before_me >= h->combine_from_callers) {
-                if (int rc = compute_combined(h->device, h->squash_base_quals, batch, likelihoods)) return rc;
-            } else if (int rc = gatk_pairhmm_compute_regions(h, 1, batch, outs)) return rc;
-        } else if (int rc = compute_shared(h, batch, likelihoods)) return rc;
+        if (int rc = compute_shared(h, batch, likelihoods)) return rc;
         h->stats = gatk_pairhmm_stats{};
         h->stats.pairs = n;
         note_call_maxima(h, *batch, read_max, hap_max);
@@ -1913,8 +1767,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) try
     else if (n == "pipeline_ramp") h->pipeline_ramp = value != 0;
     else if (n == "pipeline_depth") h->pipeline_depth = value >= 3 ? 3 : 2;
     else if (n == "pipeline_min_pairs") h->pipeline_min_pairs = std::max<int64_t>(1, static_cast<int64_t>(value));
-    else if (n == "combine_calls") h->combine_calls = static_cast<int>(value);
-    else if (n == "combine_from_callers") h->combine_from_callers = std::max(0, static_cast<int>(value));
+    else if (n == "combine_calls") h->combine_calls = value != 0;
     else if (n == "per_group_factor") h->per_group_factor = std::max<int64_t>(1, static_cast<int64_t>(value));
     else if (n == "kernel_download_bytes") h->kernel_download_bytes = static_cast<size_t>(std::max(0.0, value));
     else if (n == "signal_download_bytes") h->signal_download_bytes = static_cast<size_t>(std::max(0.0, value));
@@ -2107,7 +1960,14 @@ int gatk_pairhmm_resident_device_output(gatk_pairhmm_resident* r, void** device_
 
 }  // extern "C"
 
-// An engine of a device's dispatcher (or of the call combiner): a single-device handle that is nobody's own.
+// Test hook (not in the header): makes the share of engine `index` of the next multi-device calls end in a C++
+// exception, which must come back as an error code with every other engine's work finished.  -1 turns it off.
+extern "C" int gatk_pairhmm_debug_fail_share(int index) {
+    g_fail_share_for_test = index;
+    return GATK_PAIRHMM_OK;
+}
+
+// An engine of a device's dispatcher: a single-device handle that is nobody's own.
 int pairhmm_host::create_shared_engine(int device, bool squash, gatk_pairhmm** out) {
     const int rc = gatk_pairhmm_create(device, out);
     if (rc != GATK_PAIRHMM_OK) return rc;

@@ -162,7 +162,7 @@ struct DeviceWorker {
             std::function<void()> j = std::move(job);
             has_job = false;
             lk.unlock();
-            j();
+            try { j(); } catch (...) {}  // jobs report through what they capture; an exception must not end the process
             lk.lock();
             done = true;
             cv.notify_all();
@@ -266,7 +266,7 @@ struct gatk_pairhmm {
     unsigned next_child = 0;     // small calls go to the engines in turn
     bool stats_in_first_engine = false;  // the last call went through the resident interface, which the first engine serves
     int64_t multi_min_pairs = 8192;  // a call with fewer pairs goes to one engine on the calling thread
-    bool is_shared_engine = false;  // an engine of the call combiner, not a caller's handle
+    bool is_shared_engine = false;  // an engine of a device's dispatcher, not a caller's handle
     bool counted = false;           // counted among the live callers' handles (see release_shared_engines_if_last)
     int device = 0;
     hipStream_t stream = nullptr;
@@ -278,8 +278,7 @@ struct gatk_pairhmm {
     pairhmm_host::PinnedBuf signal_out;                              // and where such a result lands (coherent pinned memory)
     unsigned done_seq = 0;                             // value the next such download stores there
     int64_t per_group_factor = 32;  // calls with at least this many pairs per wave slot choose rows per lane per wave-group
-    int combine_calls = 0;  // 1: small compute_likelihoods calls of all threads on this device share device passes (2: through the blocking combiner)
-    int combine_from_callers = 4;  // ... once this many such calls are under way on the device; fewer run alone on their own handles
+    bool combine_calls = false;  // small compute_likelihoods calls of all threads on this device share the device's dispatcher
     bool pipeline_ramp = true;  // the first two parts of a cut call are a quarter and a half of pipeline_pairs
     int stream_lds_floor = 0;  // least LDS bytes per wave of the stream pass (caps the waves a CU holds)
     double* d_err = nullptr;

@@ -110,6 +110,7 @@ __device__ __forceinline__ void report_input_error(const DeviceBatch& B, const i
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(double& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(unsigned& x) { asm volatile("" : "+v"(x)); }
+constexpr int kFirstSpillingRowsFp64 = 10;  // from this many rows per lane on the fp64 one-haplotype pass no longer fits the register file
 
 constexpr bool is_lut(int mode) { return mode == kEmitLut4 || mode == kEmitLut5; }
 constexpr int lut_codes(int mode) { return mode == kEmitLut5 ? 5 : 4; }
@@ -648,8 +649,12 @@ __device__ __forceinline__ bool run_task(const DeviceBatch& B, const int task_id
             w.C[r] = static_cast<T>(real_next ? t2n : 0.0);
             w.D[r] = static_cast<T>(real_next ? t3n : 0.0);
             w.E[r] = static_cast<T>(t4 * t1n);
-            pin(w.A[r]); pin(w.B[r]); pin(w.C[r]); pin(w.D[r]); pin(w.E[r]); pin(w.T5[r]);
-            pin(XB[r]); pin(P[r]); pin(Q[r]);
+            // Not in the fp64 instantiations that spill registers (10 rows per lane and more): built with spills into
+            // accumulation registers, those returned wrong sums with these empty asm statements on doubles in them.
+            if constexpr (!(std::is_same<T, double>::value && K >= kFirstSpillingRowsFp64)) {
+                pin(w.A[r]); pin(w.B[r]); pin(w.C[r]); pin(w.D[r]); pin(w.E[r]); pin(w.T5[r]);
+                pin(XB[r]); pin(P[r]); pin(Q[r]);
+            }
             w.Ml[r] = static_cast<T>(0);
             w.El[r] = pad ? initD : static_cast<T>(0);  // column 0
         }
@@ -1261,7 +1266,7 @@ __device__ __forceinline__ void run_pairs(const DeviceBatch& B, const int first_
         w.C[r] = real_next ? t2n : 0.0;
         w.D[r] = real_next ? t3n : 0.0;
         w.E[r] = t4 * t1n;
-        pin(w.A[r]); pin(w.B[r]); pin(w.C[r]); pin(w.D[r]); pin(w.E[r]); pin(w.T5[r]);
+        if constexpr (K < kFirstSpillingRowsFp64) { pin(w.A[r]); pin(w.B[r]); pin(w.C[r]); pin(w.D[r]); pin(w.E[r]); pin(w.T5[r]); }
         w.Ml[r] = 0.0;
         w.El[r] = pad ? initD : 0.0;  // column 0
 #pragma unroll

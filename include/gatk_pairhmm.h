@@ -245,14 +245,11 @@ int gatk_pairhmm_device_count(int32_t* count);
  *                         slot uses one rows-per-lane value throughout, so that it costs one forward launch; a
  *                         larger one chooses the value per wave-group.
  *   "combine_calls"       default 0; 1 = gatk_pairhmm_compute_likelihoods calls too small to fill the device,
- *                         made at the same time by several threads on their own handles, are scored together:
- *                         a caller that finds one of the device's three shared engines free takes every waiting
- *                         call through one device pass, its own included, the others wait for their results;
- *                         same results and exceptions, per caller; only on handles whose other options are
- *                         the defaults, squash_base_quals aside.
- *   "combine_from_callers" default 4: with combine_calls on, a call shares passes only when at least this many such
- *                         calls are already under way on the device; with fewer it runs alone on its own handle
- *                         (2 to 8 caller threads are 5 to 20 % faster that way, 16 and more 5 % slower).  0: always share.
+ *                         made at the same time by several threads on their own handles, go through the device's
+ *                         dispatcher (see gatk_pairhmm_submit) as a submit and a fetch in one: a call that finds an
+ *                         engine free runs alone, calls that find none share the next pass; same results and
+ *                         exceptions, per caller; only on handles whose other options are the defaults,
+ *                         squash_base_quals aside.
  *   "kernel_upload_bytes" default 1048576: an upload of at most that many bytes is copied out of the pinned
  *                         staging buffer by a kernel on the compute stream instead of by the DMA engine, whose
  *                         hand-over to the first kernel costs more than the copy of a region-sized call.

@@ -55,9 +55,10 @@ def test_tickets_fetched_in_any_order(oracle):
         assert lib.gatk_pairhmm_fetch(h._h, 12345) == pairhmm.ILLEGAL_ARGUMENT
         st = h.stats()
         assert st["shared_passes"] >= 1 and st["shared_requests"] >= 7
-        # the same doubles as the blocking call
+        # the blocking call gives the same likelihoods (a pass over several regions may choose other rows per lane
+        # than a call of one: the fp32 sums then differ in their last bits)
         for k in (0, 4):
-            assert np.array_equal(h.compute_batch(regions[k]), got[k][0])
+            assert np.abs(h.compute_batch(regions[k]) - got[k][0]).max() <= 2e-6
     finally:
         h.close()
 

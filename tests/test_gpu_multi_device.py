@@ -162,3 +162,34 @@ def test_device_list_of_the_whole_node():
         h.close()
     with pytest.raises(pairhmm.DeviceError):
         HipLoglessPairHMM([0, 99])
+
+
+@pytest.mark.parametrize("share", [0, 1])
+def test_an_exception_inside_one_engines_share_comes_back_as_a_code(multi, hc_regions, share):
+    """Nothing may cross the C boundary as a C++ exception, and a failing share must not pull the other engine's
+    work from under it: the call returns an error code after both engines are done, and the handle works afterwards."""
+    lib = pairhmm.load_library()
+    regions = hc_regions[:120]
+    lib.gatk_pairhmm_debug_fail_share(share)
+    try:
+        with pytest.raises(pairhmm.DeviceError, match="injected failure"):
+            multi.compute_regions(regions)
+    finally:
+        lib.gatk_pairhmm_debug_fail_share(-1)
+    outs = multi.compute_regions(regions)
+    check_valid(regions, outs)
+
+
+def test_distinct_devices_when_the_box_has_them(hmm, hc_regions):
+    """With more than one GPU visible: a handle over every device gives what one device gives."""
+    n = pairhmm.device_count()
+    if n < 2:
+        pytest.skip("one GPU visible: the multi-device path is only exercised with device 0 listed twice")
+    regions = hc_regions[:400]
+    h = HipLoglessPairHMM(list(range(n)))
+    try:
+        assert_same(hmm.compute_regions(regions), h.compute_regions(regions))
+        tickets = [h.submit([b]) for b in regions[:2 * n]]
+        assert_same([t.fetch()[0] for t in tickets], hmm.compute_regions(regions[:2 * n]))
+    finally:
+        h.close()

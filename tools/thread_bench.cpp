@@ -3,8 +3,7 @@
 // handle option "combine_calls".  Synthetic HaplotypeCaller-sized regions: 30-100 reads of 121-151 bases,
 // 2-16 haplotypes of 250-500 bases.  usage: thread_bench REGIONS THREADS COMBINE [OPTION VALUE ...]
 // COMBINE: 0 = blocking calls, each on its own handle; 1 = blocking calls that share the device's dispatcher
-// ("combine_calls"); 2 = the same through the blocking combiner; -D = gatk_pairhmm_submit / gatk_pairhmm_fetch with D
-// regions in flight per thread.
+// ("combine_calls"); -D = gatk_pairhmm_submit / gatk_pairhmm_fetch with D regions in flight per thread.
 #include <atomic>
 #include <chrono>
 #include <cstdint>
