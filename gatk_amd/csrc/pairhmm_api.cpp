@@ -484,7 +484,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     std::vector<ReadInfo> read_info(static_cast<size_t>(total_reads));
     std::vector<StreamDesc> stream_descs;
     bool any_hap_n = false, any_hap_other = false;
-    int64_t cells = 0;
+    int64_t cells = 0, rows_used = 0, rows_allocated = 0;
     int read_cursor = 0, hap_cursor = 0;
     for (int k = 0; k < num_regions; ++k) {
         const gatk_pairhmm_batch& b = regions[k];
@@ -560,11 +560,13 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             }
             GroupDesc g{static_cast<int32_t>(segs.size()), 0, 0};
             int used = 0, max_seg = 0;
+            rows_allocated += static_cast<int64_t>(kWave) * K * nh;
             while (pos < order.size()) {
                 const int r = order[pos];
                 const int len = lens_desc[pos];
                 const int seg = (len + 1 + K) / K;  // rows >= len + 2: a pad row in front, the sum row behind
                 if (used + seg > kWave) break;
+                rows_used += static_cast<int64_t>(len) * nh;
                 segs.push_back(SegDesc{rp.read_begin + r, static_cast<uint8_t>(used), static_cast<uint8_t>(seg), static_cast<uint16_t>(len)});
                 read_info[rp.read_begin + r].rows_per_lane = K;
                 used += seg;
@@ -706,6 +708,8 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         }
     }
     R->cells = cells;
+    R->lane_rows_used = rows_used;
+    R->lane_rows_allocated = rows_allocated;
     R->total_tasks = total_tasks;
     R->total_read_bytes = total_read_bytes;
     R->num_neg_inf = static_cast<int32_t>(neg_inf_idx.size());
@@ -980,6 +984,8 @@ int digest_counters(gatk_pairhmm* h, gatk_pairhmm_resident* R, const int32_t* co
     st.wave_tasks = R->total_tasks;
     st.host_plan_ms = R->plan_ms;
     st.host_upload_ms = R->upload_ms;
+    st.lane_rows_used = R->lane_rows_used;
+    st.lane_rows_allocated = R->lane_rows_allocated;
     {
         int64_t most = -1;
         for (const Bucket& bk : R->buckets) {
@@ -1345,6 +1351,7 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
             const gatk_pairhmm_stats& st = h->stats;
             total.pairs += st.pairs; total.cells += st.cells; total.wave_tasks += st.wave_tasks;
             total.rerun_tasks += st.rerun_tasks; total.rerun_pairs += st.rerun_pairs;
+            total.lane_rows_used += st.lane_rows_used; total.lane_rows_allocated += st.lane_rows_allocated;
             total.fp32_kernel_ms += st.fp32_kernel_ms; total.fp64_kernel_ms += st.fp64_kernel_ms; total.aux_kernel_ms += st.aux_kernel_ms;
             total.timed_passes += st.timed_passes;
             total.main_rows_per_lane = st.main_rows_per_lane; total.main_emit_mode = st.main_emit_mode;
@@ -1527,6 +1534,7 @@ static int compute_regions_multi(gatk_pairhmm* h, int32_t num_regions, const gat
         const gatk_pairhmm_stats& st = h->children[d]->stats;
         total.pairs += st.pairs; total.cells += st.cells; total.wave_tasks += st.wave_tasks;
         total.rerun_tasks += st.rerun_tasks; total.rerun_pairs += st.rerun_pairs;
+        total.lane_rows_used += st.lane_rows_used; total.lane_rows_allocated += st.lane_rows_allocated;
         total.fp32_kernel_ms = std::max(total.fp32_kernel_ms, st.fp32_kernel_ms);
         total.fp64_kernel_ms = std::max(total.fp64_kernel_ms, st.fp64_kernel_ms);
         total.aux_kernel_ms = std::max(total.aux_kernel_ms, st.aux_kernel_ms);

@@ -213,6 +213,7 @@ struct gatk_pairhmm_resident {
     bool regions_are_pieces = false; // the call cut large regions by read ranges: indices count the pieces
     std::vector<int64_t> region_out_off;  // [num_regions + 1] offsets into the concatenated output
     int64_t total_pairs = 0, cells = 0, total_tasks = 0;
+    int64_t lane_rows_used = 0, lane_rows_allocated = 0;  // read rows the forward launches hold / rows their lanes offer (x haplotypes)
     int64_t total_read_bytes = 0;
     std::vector<pairhmm_host::Bucket> buckets;
     std::vector<pairhmm_hip::RegionDesc> descs;      // as uploaded, bucket by bucket

@@ -87,8 +87,9 @@ typedef struct gatk_pairhmm_stats {
     int32_t main_emit_mode;      /* 0 compares bytes, 1 same with haplotype N, 2 emission table A/C/G/T, 3 table with N */
     int32_t main_stream_pass;    /* 1: the fp32 stream pass (haplotype runs), 0: the one-haplotype pass */
     int32_t main_fp64;           /* 1: everything was scored in fp64 (force_fp64) */
-    /* Read rows the fp32 forward launches of the call gave to lanes (64 lanes x rows per lane, per wave-group and
-     * haplotype) and the rows among them that hold a row of a read's matrix: their ratio is how full the lanes ran. */
+    /* Rows the forward launches of the call offered (64 lanes x rows per lane, per wave-group and haplotype) and
+     * the rows among them that hold a base of a read: their ratio is how full the lanes ran (a read also takes a
+     * pad row and a sum row, so 151-base reads at 10 rows per lane reach 0.944). */
     int64_t lane_rows_allocated;
     int64_t lane_rows_used;
     /* Since the process started, on this handle's device: device passes run for calls that share the device's
