@@ -15,7 +15,9 @@ Two timed legs of K steps each, both bracketed by barrier + device synchronisati
 
 On rank 0 of a one-GPU run the other workloads follow, each through the host-pointer entry points (`configs`):
 the 128 x 16 CPU-sized batch, the 250 / 1000 high-indel batch with its fp64 rerun rate, a HaplotypeCaller-shaped
-stream of 2000 active regions in one compute_regions call, and one region per call.  Then the CPU baseline on a
+stream of 2000 active regions in one compute_regions call, one region per call (blocking, and with two and four regions
+in flight through submit / fetch), a region of eight samples through the region-level hook, and region-sized calls
+from 1, 4 and 16 host threads; every entry carries its fraction of the fp32 vector roof.  Then the CPU baseline on a
 bounded sample.  With N GPUs every rank scores its own batch of the default shape (pairs are independent: no
 data-path collective), so scaling is weak and value = N * cells / max-over-ranks time; the `c4` object adds the
 whole-genome-shaped 10 000 regions, sharded over the ranks with the host gather inside the clock (strong scaling).
@@ -35,7 +37,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_CELL = 12          # 8 mul + 4 add of the linear-space three-state recurrence
+EXECUTED_FLOP_PER_CELL = 9  # what the rescaled fp32 cell executes: 4 fused multiply-adds and 1 multiply
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X: 256 CU x 4 SIMD x 32 lanes x 2 FLOP x 2.4 GHz
+PEAK_FP64_VALU_TFLOPS = 78.6   # the fp64 passes: half the fp32 vector rate
 # HBM bytes of one fp32 forward launch on the default workload, from PMC counters collected in a run
 # of their own (2 x FETCH_SIZE + WRITE_SIZE); not measured live
 # (FETCH_SIZE counts a wide coalesced read at half its bytes on gfx950: doubled; both counters are in KiB)
@@ -152,10 +156,133 @@ def time_calls(call, reps, warm=3):
     return float(np.median(ts)), float(np.min(ts))
 
 
+def roof_frac(cells, seconds, peak_tflops=PEAK_FP32_VALU_TFLOPS):
+    """Fraction of the vector-ALU roof: cells x 12 FLOP over the wall (or kernel) time, against the peak."""
+    return round(cells * FLOP_PER_CELL / seconds / (peak_tflops * 1e12), 4)
+
+
 def leg(call, reps, what):
     med, best = time_calls(call, reps)
-    return {"workload": what, "pairs": call.pairs, "cells": call.cells, "wall_ms": round(med * 1e3, 4), "best_ms": round(best * 1e3, 4),
-            "gcups": round(call.cells / med / 1e9, 1), "calls_timed": reps, "path": "host arrays in, host arrays out (plan + H2D + kernels + D2H)"}
+    st = call.hmm.stats()
+    out = {"workload": what, "pairs": call.pairs, "cells": call.cells, "wall_ms": round(med * 1e3, 4), "best_ms": round(best * 1e3, 4),
+           "gcups": round(call.cells / med / 1e9, 1), "roofline_frac": roof_frac(call.cells, med), "calls_timed": reps,
+           "path": "host arrays in, host arrays out (plan + H2D + kernels + D2H)"}
+    if st["lane_rows_allocated"]:
+        out["lane_rows_used"] = round(st["lane_rows_used"] / st["lane_rows_allocated"], 4)
+    return out
+
+
+def kernel_split(device, batch):
+    """fp32 and fp64 kernel times of one resident pass over `batch` (HIP events on the engine's stream), each as a
+    fraction of its own vector-ALU peak: the fp32 passes over every cell, the fp64 passes over the cells of the pairs
+    they redo."""
+    from gatk_amd.pairhmm import HipLoglessPairHMM
+    hmm = HipLoglessPairHMM(device)
+    try:
+        hmm.set_option("timing", 1)
+        res = hmm.upload([batch])
+        for _ in range(3):
+            res.compute(sync=True)
+        st = hmm.stats()
+        res.free()
+    finally:
+        hmm.close()
+    redo_cells = st["rerun_pairs"] * (batch.cells / max(batch.num_reads * batch.num_haps, 1))
+    out = {"fp32_kernel_ms": round(st["fp32_kernel_ms"], 4), "fp32_roofline_frac": roof_frac(batch.cells, st["fp32_kernel_ms"] * 1e-3),
+           "fp64_kernel_ms": round(st["fp64_kernel_ms"], 4), "fp64_pairs": st["rerun_pairs"], "other_kernels_ms": round(st["aux_kernel_ms"], 4)}
+    if st["rerun_pairs"] and st["fp64_kernel_ms"] > 0:
+        out["fp64_roofline_frac"] = roof_frac(redo_cells, st["fp64_kernel_ms"] * 1e-3, PEAK_FP64_VALU_TFLOPS)
+        out["fp64_peak_tflops"] = PEAK_FP64_VALU_TFLOPS
+    return out
+
+
+def in_flight_leg(hmm, regions, depth):
+    """One caller thread keeps `depth` regions on the device: gatk_pairhmm_submit for region n + depth - 1 goes out
+    before gatk_pairhmm_fetch of region n."""
+    from gatk_amd import pairhmm
+    lib = pairhmm.load_library()
+    calls = [HostCall(hmm, [b], True) for b in regions]
+    tickets = [C.c_int64() for _ in calls]
+
+    def submit(k):
+        if lib.gatk_pairhmm_submit(hmm._h, 1, calls[k].cbs, calls[k].arr, C.byref(tickets[k])) != 0:
+            raise RuntimeError(lib.gatk_pairhmm_last_error().decode())
+
+    def fetch(k):
+        if lib.gatk_pairhmm_fetch(hmm._h, tickets[k]) != 0:
+            raise RuntimeError(lib.gatk_pairhmm_last_error().decode())
+
+    best = None
+    for rep in range(3):
+        t0 = time.perf_counter()
+        for k in range(len(calls)):
+            if k >= depth:
+                fetch(k - depth)
+            submit(k)
+        for k in range(max(0, len(calls) - depth), len(calls)):
+            fetch(k)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    for c in calls:
+        c.check()
+    cells = sum(c.cells for c in calls)
+    return {"workload": f"{len(calls)} of those regions from one caller thread, gatk_pairhmm_submit / gatk_pairhmm_fetch with {depth} regions in flight",
+            "us_per_region": round(best * 1e6 / len(calls), 1), "gcups": round(cells / best / 1e9, 1), "roofline_frac": roof_frac(cells, best)}
+
+
+def region_hook_leg(hmm, region, samples):
+    """A region of `samples` samples through gatk_pairhmm_initialize_region + one computeLikelihoods call per sample +
+    finalizeRegion (PairHMM.java:121-139,190), against the same reads as one sample."""
+    from gatk_amd import pairhmm
+    from gatk_amd.batch import Batch
+    lib = pairhmm.load_library()
+    out = {}
+    for s in (1, samples):
+        cuts = np.linspace(0, region.num_reads, s + 1).astype(int)
+        parts = [region.read_slice(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:])]
+        ahead = [Batch(p.read_bases, p.read_quals, p.ins_gop, p.del_gop, None, p.read_offsets, p.hap_bases, p.hap_offsets) for p in parts]
+        keep = []
+        cbs_ahead = (pairhmm.CBatch * s)(*[pairhmm.to_cbatch(b, keep) for b in ahead])
+        calls = [HostCall(hmm, [p], True) for p in parts]
+        best = None
+        for rep in range(40):
+            t0 = time.perf_counter()
+            if lib.gatk_pairhmm_initialize_region(hmm._h, s, cbs_ahead, 1000, 16000) != 0:
+                raise RuntimeError(lib.gatk_pairhmm_last_error().decode())
+            for c in calls:
+                c()
+            lib.gatk_pairhmm_finalize_region(hmm._h)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        for c in calls:
+            c.check()
+        out[s] = best
+    return {"workload": f"one region of {region.num_reads} reads x {region.num_haps} haplotypes as {samples} samples: initialize_region, "
+                        f"{samples} computeLikelihoods calls, finalizeRegion", "us_per_region": round(out[samples] * 1e6, 1),
+            "same_reads_as_one_sample_us": round(out[1] * 1e6, 1), "ratio": round(out[samples] / out[1], 3),
+            "region_hits": hmm.stats()["region_hits"]}
+
+
+def shared_device_legs():
+    """Region-sized calls from several host threads, each with its own handle, on one GPU (tools/thread_bench.cpp, a
+    C++ driver: Python threads would measure the interpreter lock).  Skipped when the driver has not been built."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "thread_bench_bin")
+    if not os.path.exists(exe):
+        return {"skipped": "tools/thread_bench_bin is not built (g++ -O2 -pthread tools/thread_bench.cpp -Lgatk_amd -lgatk_pairhmm_hip)"}
+    out = {}
+    modes = {"blocking_calls": 0, "blocking_calls_sharing_the_dispatcher": 1, "two_in_flight_per_thread": -2, "three_in_flight_per_thread": -3}
+    for threads, names in ((1, ("blocking_calls", "two_in_flight_per_thread")), (4, tuple(modes)), (16, ("blocking_calls_sharing_the_dispatcher", "two_in_flight_per_thread"))):
+        for name in names:
+            try:
+                txt = subprocess.run([exe, "2000", str(threads), str(modes[name])], capture_output=True, text=True, timeout=120, check=True).stdout
+                us = float(txt.split(" us per region")[0].split()[-1])
+                gcups = float(txt.split(" GCUPS")[0].split()[-1])
+                out[f"{threads}_threads_{name}"] = {"us_per_region": us, "gcups": gcups, "roofline_frac": round(gcups * 1e9 * FLOP_PER_CELL / (PEAK_FP32_VALU_TFLOPS * 1e12), 4)}
+            except Exception as e:  # never lose the line over the extra leg
+                out[f"{threads}_threads_{name}"] = {"error": repr(e)}
+    out["workload"] = "2000 synthetic HaplotypeCaller-sized regions (30-100 reads of 121-151 bases, 2-16 haplotypes of 250-500 bases), one region per call"
+    return out
 
 
 def other_configs(device, hc_regions):
@@ -172,6 +299,7 @@ def other_configs(device, hc_regions):
         out["c5"] = leg(call, 10, "long-read / indel stress: 4096 reads (250 bp, 4 % indels, mean Q20) x 32 haplotypes (1000 bp)")
         st = hmm.stats()
         out["c5"]["fp64_rerun"] = {"pairs": st["rerun_pairs"], "rate": round(st["rerun_pairs"] / max(call.pairs, 1), 6)}
+        out["c5"]["kernels"] = kernel_split(device, c5)
         call = HostCall(hmm, hc_regions, False)
         out["hc_2000_regions"] = leg(call, 8, f"HaplotypeCaller-shaped stream, {len(hc_regions)} active regions (30x, 121-151 bp reads, 2-32 "
                                               "haplotypes of 250-500 bp) in one compute_regions call")
@@ -190,9 +318,16 @@ def other_configs(device, hc_regions):
         cells = sum(c.cells for c in calls)
         out["one_region_per_call"] = {"workload": "300 of those regions, one compute_likelihoods call each, one caller thread",
                                       "median_us": round(float(np.median(lat)) * 1e6, 1), "p90_us": round(float(np.percentile(lat, 90)) * 1e6, 1),
-                                      "gcups": round(cells / t_all / 1e9, 1), "mean_pairs_per_call": round(sum(c.pairs for c in calls) / len(calls), 1)}
+                                      "gcups": round(cells / t_all / 1e9, 1), "roofline_frac": roof_frac(cells, t_all),
+                                      "mean_pairs_per_call": round(sum(c.pairs for c in calls) / len(calls), 1)}
+        calls = None
+        out["one_region_per_call_two_in_flight"] = in_flight_leg(hmm, hc_regions[:300], 2)
+        out["one_region_per_call_four_in_flight"] = in_flight_leg(hmm, hc_regions[:300], 4)
+        big = max(hc_regions[:300], key=lambda b: b.num_reads)
+        out["eight_sample_region"] = region_hook_leg(hmm, big, 8)
     finally:
         hmm.close()
+    out["callers_sharing_one_gpu"] = shared_device_legs()
     return out
 
 
@@ -405,7 +540,12 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
                          "traffic": PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD if default_shape else None,
                          "traffic_source": PMC_TRAFFIC_SOURCE if default_shape else None,
-                         "flop_per_cell": FLOP_PER_CELL, "kernel_ms": round(fp32_ms / steps, 4),
+                         "flop_per_cell": FLOP_PER_CELL,
+                         "flop_per_cell_executed": EXECUTED_FLOP_PER_CELL,
+                         "frac_executed": round(achieved / PEAK_FP32_VALU_TFLOPS * EXECUTED_FLOP_PER_CELL / FLOP_PER_CELL, 4),
+                         "frac_note": "frac prices the 12 FLOP of the reference's recurrence per cell; the rescaled form the kernel evaluates "
+                                      "executes 9 (4 FMA + 1 multiply), so the vector ALUs run at frac_executed of their peak",
+                         "kernel_ms": round(fp32_ms / steps, 4),
                          "kernel_gcups": round(batch.cells / kern_s / 1e9, 1)},
             "other_kernels_ms": round(aux_ms / steps, 4),
             "fp64_rerun": {"pairs_per_step": rerun_pairs // steps, "rate": round(rerun_pairs / steps / (batch.num_reads * batch.num_haps), 6),

@@ -1675,22 +1675,50 @@ int gatk_pairhmm_batch_get_result(gatk_pairhmm* h, const double** results, int64
     if (int rc = check_handle(h)) return rc;
     if (!results || !count) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "results cannot be null");
     const size_t n = h->queue.size();
-    std::vector<gatk_pairhmm_batch> regions(n);
-    std::vector<std::vector<int32_t>> ro(n);
-    std::vector<double*> outs(n);
     int64_t total = 0;
     for (size_t k = 0; k < n; ++k) total += static_cast<int64_t>(h->queue[k].hap_off.size()) - 1;
     h->queue_results.assign(static_cast<size_t>(total), 0.0);
+    // Queued reads that follow one another with byte-identical haplotype lists (the usual case: every read of a
+    // region is added against the region's haplotypes) become ONE region: its reads then share wave-groups and
+    // haplotype runs, instead of one 16-lane read per wavefront.  The results of a region are read-major, which is
+    // the queue's order: haplotype-minor per queued read.
+    struct Merged {
+        std::vector<uint8_t> bases, quals, ins, del, gcp;
+        std::vector<int32_t> read_off{0};
+        const gatk_pairhmm::Queued* haps = nullptr;
+    };
+    std::vector<Merged> merged;
+    std::vector<int64_t> merged_out;
     int64_t off = 0;
     for (size_t k = 0; k < n; ++k) {
-        auto& q = h->queue[k];
-        ro[k] = {0, static_cast<int32_t>(q.bases.size()) - 1};
-        regions[k] = gatk_pairhmm_batch{1, static_cast<int32_t>(q.hap_off.size()) - 1, q.bases.data(), q.quals.data(), q.ins.data(),
-                                        q.del.data(), q.gcp.data(), ro[k].data(), q.haps.data(), q.hap_off.data()};
-        outs[k] = h->queue_results.data() + off;
-        off += regions[k].num_haps;
+        const gatk_pairhmm::Queued& q = h->queue[k];
+        const bool same = !merged.empty() && merged.back().haps->hap_off == q.hap_off && merged.back().haps->haps == q.haps;
+        if (!same) {
+            merged.emplace_back();
+            merged.back().haps = &q;
+            merged_out.push_back(off);
+        }
+        Merged& m = merged.back();
+        const size_t len = q.bases.size() - 1;  // every queued array carries one byte of padding
+        m.bases.insert(m.bases.end(), q.bases.begin(), q.bases.begin() + len);
+        m.quals.insert(m.quals.end(), q.quals.begin(), q.quals.begin() + len);
+        m.ins.insert(m.ins.end(), q.ins.begin(), q.ins.begin() + len);
+        m.del.insert(m.del.end(), q.del.begin(), q.del.begin() + len);
+        m.gcp.insert(m.gcp.end(), q.gcp.begin(), q.gcp.begin() + len);
+        m.read_off.push_back(static_cast<int32_t>(m.bases.size()));
+        off += static_cast<int64_t>(q.hap_off.size()) - 1;
     }
-    const int rc = n ? gatk_pairhmm_compute_regions(h, static_cast<int32_t>(n), regions.data(), outs.data()) : GATK_PAIRHMM_OK;
+    std::vector<gatk_pairhmm_batch> regions(merged.size());
+    std::vector<double*> outs(merged.size());
+    for (size_t g = 0; g < merged.size(); ++g) {
+        Merged& m = merged[g];
+        for (auto* v : {&m.bases, &m.quals, &m.ins, &m.del, &m.gcp}) v->push_back(0);  // data pointers stay non-null for empty reads
+        regions[g] = gatk_pairhmm_batch{static_cast<int32_t>(m.read_off.size()) - 1, static_cast<int32_t>(m.haps->hap_off.size()) - 1,
+                                        m.bases.data(), m.quals.data(), m.ins.data(), m.del.data(), m.gcp.data(), m.read_off.data(),
+                                        m.haps->haps.data(), m.haps->hap_off.data(), nullptr};
+        outs[g] = h->queue_results.data() + merged_out[g];
+    }
+    const int rc = n ? gatk_pairhmm_compute_regions(h, static_cast<int32_t>(regions.size()), regions.data(), outs.data()) : GATK_PAIRHMM_OK;
     h->queue.clear();
     if (rc) return rc;
     *results = h->queue_results.data();

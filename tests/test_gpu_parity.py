@@ -309,6 +309,64 @@ def test_batch_pair_hmm_interface(hmm, oracle):
     assert hmm.batchGetResult().shape == (0,)  # queue was cleared
 
 
+def test_batch_pair_hmm_reads_against_one_haplotype_list_run_as_one_region(oracle):
+    """BatchPairHMM.batchAdd once per read of a region against the region's haplotypes (BatchPairHMM.java:33-40):
+    the queued reads are scored as one region, so batchGetResult returns what one computeLikelihoods call over the
+    same reads returns, in about the same time; a change of haplotype list in the middle starts a new region."""
+    import time
+    b = max(synth.make_regions(6, seed=123, coverage=28, read_len=140), key=lambda x: x.num_reads)
+    other = synth.make_regions(1, seed=124, coverage=6, read_len=100)[0]
+    assert b.num_reads >= 40
+
+    def reads_of(x):
+        o = x.read_offsets
+        return [(bytes(x.read_bases[o[r]:o[r + 1]]), x.read_quals[o[r]:o[r + 1]], x.ins_gop[o[r]:o[r + 1]], x.del_gop[o[r]:o[r + 1]],
+                 x.gcp[o[r]:o[r + 1]]) for r in range(x.num_reads)]
+
+    def haps_of(x):
+        o = x.hap_offsets
+        return [bytes(x.hap_bases[o[a]:o[a + 1]]) for a in range(x.num_haps)]
+
+    h = pairhmm.HipLoglessPairHMM(0)
+    try:
+        whole = h.compute_batch(b)
+        for rd in reads_of(b):
+            h.batchAdd(haps_of(b), *rd)
+        got = h.batchGetResult()
+        assert np.array_equal(got, whole.reshape(-1))
+        assert h.stats()["pairs"] == b.num_reads * b.num_haps  # one region, not one per read
+        assert_parity(got.reshape(whole.shape), ref(oracle, b))
+        # two lists in turn: the first half of b, all of `other`, the second half of b
+        half = b.num_reads // 2
+        for rd in reads_of(b)[:half]:
+            h.batchAdd(haps_of(b), *rd)
+        for rd in reads_of(other):
+            h.batchAdd(haps_of(other), *rd)
+        for rd in reads_of(b)[half:]:
+            h.batchAdd(haps_of(b), *rd)
+        got = h.batchGetResult()
+        n1, n2 = half * b.num_haps, other.num_reads * other.num_haps
+        want = np.concatenate([ref(oracle, b).reshape(-1)[:n1], ref(oracle, other).reshape(-1), ref(oracle, b).reshape(-1)[n1:]])
+        assert got.shape == want.shape
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin) and np.abs(got[fin] - want[fin]).max() <= TOL
+        assert n2 > 0
+        # time: the queue against one call (marshalling of the adds not counted: the clock is on batchGetResult)
+        keep, best_q, best_c = reads_of(b), 1e9, 1e9
+        for _ in range(5):
+            for rd in keep:
+                h.batchAdd(haps_of(b), *rd)
+            t0 = time.perf_counter()
+            h.batchGetResult()
+            best_q = min(best_q, time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            h.compute_batch(b)
+            best_c = min(best_c, time.perf_counter() - t0)
+        assert best_q <= 1.3 * best_c + 30e-6, (best_q, best_c)
+    finally:
+        h.close()
+
+
 def test_pointer_array_entry_point(hmm, oracle):
     b = synth.make_batch(9, 4, 50, 100, seed=8, len_jitter=30)
     lib = pairhmm.load_library()
