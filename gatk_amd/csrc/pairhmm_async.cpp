@@ -235,8 +235,35 @@ bool same_or_default(const uint8_t* a, const uint8_t* b, size_t n, uint8_t dflt)
     return true;
 }
 
+// Base quality as the kernels use it (pairhmm_device.h, effective_qual): capped by the read's mapping quality when
+// one is given, then squashed to the minimum usable quality when under the threshold and the handle asks for it.
+inline unsigned effective_qual(unsigned q, unsigned mapq, bool squash) {
+    q = q < mapq ? q : mapq;
+    return squash && q < kBaseQualityScoreThreshold ? kMinUsableQScore : q;
+}
+
+// Base qualities of two batches with the same read lengths: the same bytes, or, where a mapping-quality cap or the
+// squashing option is in play, the same qualities once those have been applied (a caller may send a region's raw
+// reads ahead with their mapping qualities and ask with the qualities it has capped and squashed itself).
+bool same_base_quals(const gatk_pairhmm_batch& kept, const gatk_pairhmm_batch& asked, int32_t asked_base, bool squash) {
+    const int nr = kept.num_reads;
+    const size_t rbytes = static_cast<size_t>(kept.read_offsets[nr]);
+    const uint8_t* const aq = asked.read_quals + asked_base;
+    if (memcmp(kept.read_quals, aq, rbytes) == 0 && same_or_default(kept.read_mapq, asked.read_mapq, static_cast<size_t>(nr), 255)) return true;
+    if (!squash && !kept.read_mapq && !asked.read_mapq) return false;
+    for (int r = 0; r < nr; ++r) {
+        const unsigned km = kept.read_mapq ? kept.read_mapq[r] : 255u, am = asked.read_mapq ? asked.read_mapq[r] : 255u;
+        for (int32_t i = kept.read_offsets[r]; i < kept.read_offsets[r + 1]; ++i) {
+            // 255 is the out-of-bounds quality whatever the cap: it must reach the kernels' check as it is
+            if ((kept.read_quals[i] == 255) != (aq[i] == 255)) return false;
+            if (effective_qual(kept.read_quals[i], km, squash) != effective_qual(aq[i], am, squash)) return false;
+        }
+    }
+    return true;
+}
+
 // Does `asked` describe exactly the computation `kept` (a region sent ahead) stands for?
-bool same_inputs(const gatk_pairhmm_batch& kept, const gatk_pairhmm_batch& asked) {
+bool same_inputs(const gatk_pairhmm_batch& kept, const gatk_pairhmm_batch& asked, bool squash) {
     if (kept.num_reads != asked.num_reads || kept.num_haps != asked.num_haps) return false;
     if (asked.num_reads <= 0 || asked.num_haps <= 0 || !asked.read_offsets || !asked.hap_offsets || !asked.read_bases || !asked.read_quals || !asked.hap_bases)
         return false;
@@ -247,12 +274,11 @@ bool same_inputs(const gatk_pairhmm_batch& kept, const gatk_pairhmm_batch& asked
     for (int a = 1; a <= nh; ++a)
         if (asked.hap_offsets[a] - hb != kept.hap_offsets[a]) return false;
     const size_t rbytes = static_cast<size_t>(kept.read_offsets[nr]), hbytes = static_cast<size_t>(kept.hap_offsets[nh]);
-    return memcmp(kept.read_bases, asked.read_bases + rb, rbytes) == 0 && memcmp(kept.read_quals, asked.read_quals + rb, rbytes) == 0 &&
-           memcmp(kept.hap_bases, asked.hap_bases + hb, hbytes) == 0 &&
+    return memcmp(kept.read_bases, asked.read_bases + rb, rbytes) == 0 && memcmp(kept.hap_bases, asked.hap_bases + hb, hbytes) == 0 &&
            same_or_default(kept.ins_gop, asked.ins_gop ? asked.ins_gop + rb : nullptr, rbytes, kDefaultIndelQual) &&
            same_or_default(kept.del_gop, asked.del_gop ? asked.del_gop + rb : nullptr, rbytes, kDefaultIndelQual) &&
            same_or_default(kept.gcp, asked.gcp ? asked.gcp + rb : nullptr, rbytes, kDefaultGcp) &&
-           same_or_default(kept.read_mapq, asked.read_mapq, static_cast<size_t>(nr), 255);
+           same_base_quals(kept, asked, rb, squash);
 }
 
 // The library's own copy of the regions of a submit call.  own_results: the results stay with the request
@@ -452,10 +478,11 @@ int serve_from_region(gatk_pairhmm* h, const gatk_pairhmm_batch* batch, double* 
     if (it == h->tickets.end()) return GATK_PAIRHMM_OK;
     AsyncRequest* q = it->second.get();
     const int n = static_cast<int>(q->batches.size());
+    const bool squash = (h->children.empty() ? h : h->children[0])->squash_base_quals;
     int found = -1;
     for (int step = 0; step < n && found < 0; ++step) {  // samples are asked for in the order they were sent: try that one first
         const int s = (h->region_next_sample + step) % n;
-        if (q->batches[s].num_reads > 0 && same_inputs(q->batches[s], *batch)) found = s;
+        if (q->batches[s].num_reads > 0 && same_inputs(q->batches[s], *batch, squash)) found = s;
     }
     if (found < 0) { ++h->region_misses; return GATK_PAIRHMM_OK; }
     if (!h->region_fetched) {

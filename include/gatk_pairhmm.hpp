@@ -3,15 +3,18 @@
 // The reference's host side is Java (pairhmm/PairHMM.java); where no JDK is available this header
 // is the host-side stand-in with the same method names, argument meaning and error behaviour:
 //   initialize(readMaxLength, haplotypeMaxLength)            PairHMM.java:104
+//   initialize(haplotypes, perSampleReadList, readMax, hapMax) PairHMM.java:137 (the region-level hook)
 //   computeLikelihoods(matrix, reads, gcp)                   PairHMM.java:190
 //   getLikelihoodArray()                                     PairHMM.java:360
 //   finalizeRegion() / close()                               PairHMM.java:124 / :364
 //   batchAdd(...) / batchGetResult()                         BatchPairHMM.java:33-40
+//   submit(...) / fetch(ticket)                              computeLikelihoods in two halves (no counterpart in the reference)
 // Java exceptions become C++ exceptions of the same name.  Header-only; link libgatk_pairhmm_hip.so.
 #pragma once
 
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -64,40 +67,58 @@ public:
 
     void initialize(int readMaxLength, int haplotypeMaxLength) { check(gatk_pairhmm_initialize(h_, readMaxLength, haplotypeMaxLength)); }
 
+    // PairHMM.initialize(haplotypes, perSampleReadList, readMaxLength, haplotypeMaxLength), PairHMM.java:137: every
+    // sample's reads and the region's haplotypes go to the device in one pass; returns without waiting for it.  The
+    // computeLikelihoods calls that follow (one per sample, PairHMM.java:190) find their likelihoods there.
+    void initialize(const std::vector<Bytes>& haplotypes, const std::map<std::string, std::vector<Read>>& perSampleReadList,
+                    int readMaxLength, int haplotypeMaxLength) {
+        std::vector<Flat> flats;
+        flats.reserve(perSampleReadList.size());
+        std::vector<gatk_pairhmm_batch> batches;
+        for (const auto& sample : perSampleReadList) {
+            flats.emplace_back(sample.second, nullptr, haplotypes);  // no GCP yet: it comes with computeLikelihoods
+            batches.push_back(flats.back().batch());
+        }
+        check(gatk_pairhmm_initialize_region(h_, static_cast<int32_t>(batches.size()), batches.data(), readMaxLength, haplotypeMaxLength));
+    }
+
     // gcp: per-read gap-continuation penalties (the Map<GATKSAMRecord, byte[]> of the reference),
     // indexed like `reads`.
     void computeLikelihoods(LikelihoodMatrix& likelihoods, const std::vector<Read>& reads, const std::vector<Bytes>& gcp) {
         if (reads.empty()) return;  // PairHMM.java:193
         const auto& alleles = likelihoods.alleles();
-        Bytes rb, rq, ri, rd, rg, hb;
-        std::vector<int32_t> ro{0}, ho{0};
-        for (size_t r = 0; r < reads.size(); ++r) {
-            const Read& x = reads[r];
-            const size_t n = x.bases.size();
-            // PairHMM.java:276-279
-            if (x.quals.size() != n) throw IllegalArgumentException("Read bases and read quals aren't the same size");
-            if (x.insertionQuals.size() != n) throw IllegalArgumentException("Read bases and read insertion quals aren't the same size");
-            if (x.deletionQuals.size() != n) throw IllegalArgumentException("Read bases and read deletion quals aren't the same size");
-            if (gcp.at(r).size() != n) throw IllegalArgumentException("Read bases and overall GCP aren't the same size");
-            rb.insert(rb.end(), x.bases.begin(), x.bases.end());
-            rq.insert(rq.end(), x.quals.begin(), x.quals.end());
-            ri.insert(ri.end(), x.insertionQuals.begin(), x.insertionQuals.end());
-            rd.insert(rd.end(), x.deletionQuals.begin(), x.deletionQuals.end());
-            rg.insert(rg.end(), gcp[r].begin(), gcp[r].end());
-            ro.push_back(static_cast<int32_t>(rb.size()));
-        }
-        for (const Bytes& a : alleles) {
-            hb.insert(hb.end(), a.begin(), a.end());
-            ho.push_back(static_cast<int32_t>(hb.size()));
-        }
-        for (Bytes* v : {&rb, &rq, &ri, &rd, &rg, &hb}) v->push_back(0);
-        gatk_pairhmm_batch b{static_cast<int32_t>(reads.size()), static_cast<int32_t>(alleles.size()), rb.data(), rq.data(), ri.data(),
-                             rd.data(), rg.data(), ro.data(), hb.data(), ho.data()};
+        const Flat f(reads, &gcp, alleles);
+        const gatk_pairhmm_batch b = f.batch();
         mLikelihoodArray_.assign(reads.size() * alleles.size(), 0.0);
         check(gatk_pairhmm_compute_likelihoods(h_, &b, mLikelihoodArray_.data()));
         size_t idx = 0;
         for (size_t r = 0; r < reads.size(); ++r)
             for (size_t a = 0; a < alleles.size(); ++a) likelihoods.set(a, r, mLikelihoodArray_[idx++]);  // PairHMM.java:224-225
+    }
+
+    // computeLikelihoods in two halves: submit returns a ticket at once, fetch(ticket) fills the matrix.  The reads and
+    // the GCP arrays may go away after submit; the matrix must live until fetch.
+    struct Ticket {
+        int64_t id = 0;
+        LikelihoodMatrix* matrix = nullptr;
+        std::vector<double> values;  // read-major, written by the engine
+    };
+    std::unique_ptr<Ticket> submit(LikelihoodMatrix& likelihoods, const std::vector<Read>& reads, const std::vector<Bytes>& gcp) {
+        std::unique_ptr<Ticket> t(new Ticket());
+        t->matrix = &likelihoods;
+        t->values.assign(reads.size() * likelihoods.alleleCount(), 0.0);
+        const Flat f(reads, &gcp, likelihoods.alleles());
+        const gatk_pairhmm_batch b = f.batch();
+        double* out = t->values.data();
+        check(gatk_pairhmm_submit(h_, 1, &b, &out, &t->id));
+        return t;
+    }
+    void fetch(Ticket& t) {
+        check(gatk_pairhmm_fetch(h_, t.id));
+        const size_t alleles = t.matrix->alleleCount(), reads = t.matrix->readCount();
+        size_t idx = 0;
+        for (size_t r = 0; r < reads; ++r)
+            for (size_t a = 0; a < alleles; ++a) t.matrix->set(a, r, t.values[idx++]);
     }
 
     const std::vector<double>& getLikelihoodArray() const { return mLikelihoodArray_; }
@@ -126,6 +147,38 @@ public:
     }
 
     gatk_pairhmm* handle() const { return h_; }
+
+    // The concatenated arrays of one computeLikelihoods call (gatk_pairhmm_batch) with the checks of PairHMM.java:276-279.
+    struct Flat {
+        Bytes rb, rq, ri, rd, rg, hb;
+        std::vector<int32_t> ro{0}, ho{0};
+        bool has_gcp = false;
+        Flat(const std::vector<Read>& reads, const std::vector<Bytes>* gcp, const std::vector<Bytes>& alleles) : has_gcp(gcp != nullptr) {
+            for (size_t r = 0; r < reads.size(); ++r) {
+                const Read& x = reads[r];
+                const size_t n = x.bases.size();
+                if (x.quals.size() != n) throw IllegalArgumentException("Read bases and read quals aren't the same size");
+                if (x.insertionQuals.size() != n) throw IllegalArgumentException("Read bases and read insertion quals aren't the same size");
+                if (x.deletionQuals.size() != n) throw IllegalArgumentException("Read bases and read deletion quals aren't the same size");
+                if (gcp && gcp->at(r).size() != n) throw IllegalArgumentException("Read bases and overall GCP aren't the same size");
+                rb.insert(rb.end(), x.bases.begin(), x.bases.end());
+                rq.insert(rq.end(), x.quals.begin(), x.quals.end());
+                ri.insert(ri.end(), x.insertionQuals.begin(), x.insertionQuals.end());
+                rd.insert(rd.end(), x.deletionQuals.begin(), x.deletionQuals.end());
+                if (gcp) rg.insert(rg.end(), (*gcp)[r].begin(), (*gcp)[r].end());
+                ro.push_back(static_cast<int32_t>(rb.size()));
+            }
+            for (const Bytes& a : alleles) {
+                hb.insert(hb.end(), a.begin(), a.end());
+                ho.push_back(static_cast<int32_t>(hb.size()));
+            }
+            for (Bytes* v : {&rb, &rq, &ri, &rd, &rg, &hb}) v->push_back(0);  // data pointers stay non-null
+        }
+        gatk_pairhmm_batch batch() const {
+            return gatk_pairhmm_batch{static_cast<int32_t>(ro.size()) - 1, static_cast<int32_t>(ho.size()) - 1, rb.data(), rq.data(), ri.data(),
+                                      rd.data(), has_gcp ? rg.data() : nullptr, ro.data(), hb.data(), ho.data(), nullptr};
+        }
+    };
 
     static void check(int rc) {
         if (rc == GATK_PAIRHMM_OK) return;

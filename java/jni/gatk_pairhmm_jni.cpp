@@ -50,6 +50,12 @@ bool flatten(JNIEnv* env, jobjectArray arrays, std::vector<uint8_t>& data, std::
 
 gatk_pairhmm* H(jlong h) { return reinterpret_cast<gatk_pairhmm*>(h); }
 
+// An outstanding jniSubmit: the engine's ticket and the array the engine writes the likelihoods into.
+struct PendingResult {
+    int64_t ticket = 0;
+    std::vector<double> values;
+};
+
 // PairHMM.java:276-279: every per-read array must be as long as the read's bases.  The Java class checks this
 // too; a caller that reaches the native method some other way gets the same exception instead of misaligned bytes.
 bool same_lengths(JNIEnv* env, const std::vector<int32_t>& bases, const std::vector<int32_t>& other, const char* what) {
@@ -118,6 +124,83 @@ JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPair
     std::vector<double> out(static_cast<size_t>(b.num_reads) * b.num_haps);
     if (const int rc = gatk_pairhmm_compute_likelihoods(H(h), &b, out.data())) { throw_for(env, rc); return; }
     env->SetDoubleArrayRegion(likelihoodArray, 0, static_cast<jsize>(out.size()), out.data());
+}
+
+// PairHMM.initialize(haplotypes, perSampleReadList, readMaxLength, haplotypeMaxLength), PairHMM.java:137: the reads of
+// all samples arrive sample after sample in one set of arrays with the per-sample counts beside them; every sample
+// becomes one gatk_pairhmm_batch whose offset table is a window of the common one (offsets need not start at 0).
+JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniInitializeRegion(
+    JNIEnv* env, jclass, jlong h, jintArray readsPerSample, jobjectArray readBases, jobjectArray readQuals, jobjectArray insGOP,
+    jobjectArray delGOP, jbyteArray mappingQualities, jobjectArray hapBases, jint readMax, jint hapMax) {
+    std::vector<uint8_t> rb, rq, ri, rd, hb, mq;
+    std::vector<int32_t> ro, oq, oi, od, ho;
+    if (!readsPerSample || !flatten(env, readBases, rb, ro) || !flatten(env, readQuals, rq, oq) || !flatten(env, insGOP, ri, oi) ||
+        !flatten(env, delGOP, rd, od) || !flatten(env, hapBases, hb, ho)) {
+        env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "readBases cannot be null");
+        return;
+    }
+    if (!same_lengths(env, ro, oq, "read quals") || !same_lengths(env, ro, oi, "read insertion quals") || !same_lengths(env, ro, od, "read deletion quals"))
+        return;
+    std::vector<int32_t> counts(static_cast<size_t>(env->GetArrayLength(readsPerSample)) + 1);
+    env->GetIntArrayRegion(readsPerSample, 0, static_cast<jsize>(counts.size()) - 1, reinterpret_cast<jint*>(counts.data()));
+    counts.pop_back();
+    const int64_t total = static_cast<int64_t>(ro.size()) - 1;
+    if (mappingQualities) {
+        if (env->GetArrayLength(mappingQualities) != total) {
+            env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "one mapping quality per read is required");
+            return;
+        }
+        mq.resize(static_cast<size_t>(total) + 1);
+        env->GetByteArrayRegion(mappingQualities, 0, static_cast<jsize>(total), reinterpret_cast<jbyte*>(mq.data()));
+    }
+    std::vector<gatk_pairhmm_batch> samples;
+    int64_t first = 0;
+    for (const int32_t n : counts) {
+        if (n < 0 || first + n > total) {
+            env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "the per-sample read counts do not add up to the number of reads");
+            return;
+        }
+        samples.push_back(gatk_pairhmm_batch{n, static_cast<int32_t>(ho.size()) - 1, rb.data(), rq.data(), ri.data(), rd.data(), nullptr,
+                                             ro.data() + first, hb.data(), ho.data(), mq.empty() ? nullptr : mq.data() + first});
+        first += n;
+    }
+    // the engine copies what it is given before it returns: the vectors above may go
+    if (const int rc = gatk_pairhmm_initialize_region(H(h), static_cast<int32_t>(samples.size()), samples.data(), readMax, hapMax)) throw_for(env, rc);
+}
+
+JNIEXPORT jlong JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniSubmit(
+    JNIEnv* env, jclass, jlong h, jobjectArray readBases, jobjectArray readQuals, jobjectArray insGOP, jobjectArray delGOP,
+    jobjectArray gcp, jobjectArray hapBases) {
+    std::vector<uint8_t> rb, rq, ri, rd, rg, hb;
+    std::vector<int32_t> ro, oq, oi, od, og, ho;
+    if (!flatten(env, readBases, rb, ro) || !flatten(env, readQuals, rq, oq) || !flatten(env, insGOP, ri, oi) ||
+        !flatten(env, delGOP, rd, od) || !flatten(env, gcp, rg, og) || !flatten(env, hapBases, hb, ho)) {
+        env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "readBases cannot be null");
+        return 0;
+    }
+    if (!same_lengths(env, ro, oq, "read quals") || !same_lengths(env, ro, oi, "read insertion quals") ||
+        !same_lengths(env, ro, od, "read deletion quals") || !same_lengths(env, ro, og, "overall GCP"))
+        return 0;
+    gatk_pairhmm_batch b{static_cast<int32_t>(ro.size()) - 1, static_cast<int32_t>(ho.size()) - 1, rb.data(), rq.data(), ri.data(),
+                         rd.data(), rg.data(), ro.data(), hb.data(), ho.data(), nullptr};
+    // the likelihoods land in memory this veneer owns until jniFetch hands them to the Java array
+    PendingResult* pending = new PendingResult();
+    pending->values.assign(static_cast<size_t>(b.num_reads) * static_cast<size_t>(b.num_haps), 0.0);
+    double* out = pending->values.data();
+    if (const int rc = gatk_pairhmm_submit(H(h), 1, &b, &out, &pending->ticket)) { delete pending; throw_for(env, rc); return 0; }
+    return reinterpret_cast<jlong>(pending);
+}
+
+JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniFetch(JNIEnv* env, jclass, jlong h, jlong ticket, jdoubleArray likelihoodArray) {
+    PendingResult* pending = reinterpret_cast<PendingResult*>(ticket);
+    if (!pending) { env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "no such ticket"); return; }
+    const int rc = gatk_pairhmm_fetch(H(h), pending->ticket);
+    if (rc) throw_for(env, rc);
+    else if (static_cast<size_t>(env->GetArrayLength(likelihoodArray)) != pending->values.size())
+        env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "likelihoodArray has the wrong length for this ticket");
+    else if (!pending->values.empty())
+        env->SetDoubleArrayRegion(likelihoodArray, 0, static_cast<jsize>(pending->values.size()), pending->values.data());
+    delete pending;
 }
 
 JNIEXPORT jdouble JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniComputePair(
@@ -241,6 +324,10 @@ JNIEXPORT jobjectArray JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipRes
 JNIEXPORT jobjectArray JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipResidentReadLikelihoods_jniResidentMarginalize(
     JNIEnv* env, jclass, jlong p, jintArray oldToNew, jint newAlleleCount) {
     ResidentRegions* r = RR(p);
+    if (newAlleleCount < 0 || !oldToNew) {
+        env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "the new allele count cannot be negative and the index map cannot be null");
+        return nullptr;
+    }
     std::vector<int32_t> map(static_cast<size_t>(env->GetArrayLength(oldToNew)) + 1);
     env->GetIntArrayRegion(oldToNew, 0, static_cast<jsize>(map.size()) - 1, reinterpret_cast<jint*>(map.data()));
     std::vector<std::vector<double>> outs(r->samples.size());

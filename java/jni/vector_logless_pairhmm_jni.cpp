@@ -115,6 +115,8 @@ JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_VectorLoglessP
     if (numReads <= 0) return;  // PairHMM.java:193
     gatk_pairhmm* h = handle_of_this_thread();
     if (!h) { throw_for(env, GATK_PAIRHMM_DEVICE_ERROR); return; }
+    // every pinned byte[] keeps a local reference until the call ends: far more than the 16 a native frame is promised
+    if (env->EnsureLocalCapacity(5 * numReads + numHaplotypes + 16) != 0) return;  // OutOfMemoryError is pending
     PinnedArrays bases(env), quals(env), ins(env), del(env), gcp(env), haps(env);
     for (jint r = 0; r < numReads; ++r) {
         jobject holder = env->GetObjectArrayElement(readDataArray, r);

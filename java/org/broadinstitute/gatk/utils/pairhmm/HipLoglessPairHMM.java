@@ -44,6 +44,12 @@ public class HipLoglessPairHMM extends PairHMM {
                                                      byte[][] haplotypeBases, double[] likelihoodArray);
     private static native double jniComputePair(long handle, byte[] haplotypeBases, byte[] readBases, byte[] readQuals,
                                                 byte[] insertionGOP, byte[] deletionGOP, byte[] overallGCP); // gatk_pairhmm_compute_pair
+    private static native void jniInitializeRegion(long handle, int[] readsPerSample,    // gatk_pairhmm_initialize_region: the reads of all samples, sample after sample
+                                                   byte[][] readBases, byte[][] readQuals, byte[][] insertionGOP, byte[][] deletionGOP,
+                                                   byte[] mappingQualities, byte[][] haplotypeBases, int readMax, int hapMax);
+    private static native long jniSubmit(long handle, byte[][] readBases, byte[][] readQuals,     // gatk_pairhmm_submit: returns a ticket
+                                         byte[][] insertionGOP, byte[][] deletionGOP, byte[][] overallGCP, byte[][] haplotypeBases);
+    private static native void jniFetch(long handle, long ticket, double[] likelihoodArray);     // gatk_pairhmm_fetch
     private static native void jniFinalizeRegion(long handle);                          // gatk_pairhmm_finalize_region
     private static native void jniClose(long handle);                                   // gatk_pairhmm_close
 
@@ -80,12 +86,51 @@ public class HipLoglessPairHMM extends PairHMM {
         jniInitialize(handle, readMaxLength, haplotypeMaxLength);
     }
 
+    /** When set, the region-level hook sends each read's mapping quality along and the engine caps the base qualities
+     *  by it and squashes the ones under BASE_QUALITY_SCORE_THRESHOLD (PairHMM.java:54), which is what the upstream
+     *  likelihood engine does to a read between this call and computeLikelihoods: the reads it then passes compare
+     *  equal, after the same treatment, to the ones sent ahead. */
+    private boolean sendMappingQualities = false;
+
+    public void setSendMappingQualities(final boolean value) {
+        sendMappingQualities = value;
+        jniSetOption(handle, "squash_base_quals", value ? 1.0 : 0.0);
+    }
+
+    /** PairHMM.java:129-139, "used by the JNI implementations to transfer all data once to the native code": every
+     *  sample's reads and the region's haplotypes go to the GPU in ONE pass, which is started here and not waited for.
+     *  Each computeLikelihoods call that follows (one per sample) finds its likelihoods there; a call whose reads
+     *  differ from the ones sent (another GCP than the constant 10, qualities changed in a way the engine does not
+     *  reproduce) is scored on its own, so the results never depend on this call having been made. */
     @Override
     public void initialize(final List<Haplotype> haplotypes, final Map<String, List<GATKSAMRecord>> perSampleReadList,
                            final int readMaxLength, final int haplotypeMaxLength) {
-        // Nothing is sent ahead of time: each computeLikelihoods call carries its own bytes (a few MB
-        // over PCIe against milliseconds of kernel time).
-        initialize(readMaxLength, haplotypeMaxLength);
+        super.initialize(readMaxLength, haplotypeMaxLength);
+        int total = 0;
+        for (final List<GATKSAMRecord> reads : perSampleReadList.values())
+            total += reads.size();
+        final int[] readsPerSample = new int[perSampleReadList.size()];
+        final byte[][] readBases = new byte[total][];
+        final byte[][] readQuals = new byte[total][];
+        final byte[][] insGOP = new byte[total][];
+        final byte[][] delGOP = new byte[total][];
+        final byte[] mapq = sendMappingQualities ? new byte[total] : null;
+        int s = 0, r = 0;
+        for (final List<GATKSAMRecord> reads : perSampleReadList.values()) {
+            readsPerSample[s++] = reads.size();
+            for (final GATKSAMRecord read : reads) {
+                readBases[r] = read.getReadBases();
+                readQuals[r] = read.getBaseQualities();
+                insGOP[r] = read.getBaseInsertionQualities();
+                delGOP[r] = read.getBaseDeletionQualities();
+                if (mapq != null) mapq[r] = (byte) Math.min(read.getMappingQuality(), 254);
+                r++;
+            }
+        }
+        final byte[][] hapBases = new byte[haplotypes.size()][];
+        for (int a = 0; a < hapBases.length; a++)
+            hapBases[a] = haplotypes.get(a).getBases();
+        jniInitializeRegion(handle, readsPerSample, readBases, readQuals, insGOP, delGOP, mapq, hapBases, readMaxLength, haplotypeMaxLength);
     }
 
     /** Same contract as PairHMM.computeLikelihoods (PairHMM.java:190-236): fills likelihoods.set(a, r, lk)
@@ -136,6 +181,48 @@ public class HipLoglessPairHMM extends PairHMM {
             threadLocalPairHMMComputeTimeDiff = (System.nanoTime() - startTime);
             pairHMMComputeTime += threadLocalPairHMMComputeTimeDiff;
         }
+    }
+
+    /** computeLikelihoods in two halves, for a caller that keeps the next region on the GPU while it consumes this one:
+     *  submit returns at once; fetch fills the matrix and mLikelihoodArray as computeLikelihoods would have. */
+    public static final class Ticket {
+        private final long id;
+        private final ReadLikelihoods.Matrix<Haplotype> likelihoods;
+        private final int readCount, alleleCount;
+        private Ticket(final long id, final ReadLikelihoods.Matrix<Haplotype> likelihoods, final int readCount, final int alleleCount) {
+            this.id = id; this.likelihoods = likelihoods; this.readCount = readCount; this.alleleCount = alleleCount;
+        }
+    }
+
+    public Ticket submit(final ReadLikelihoods.Matrix<Haplotype> likelihoods, final List<GATKSAMRecord> processedReads,
+                         final Map<GATKSAMRecord, byte[]> gcp) {
+        final List<Haplotype> alleles = likelihoods.alleles();
+        final int readCount = processedReads.size(), alleleCount = alleles.size();
+        final byte[][] readBases = new byte[readCount][], readQuals = new byte[readCount][], insGOP = new byte[readCount][],
+                       delGOP = new byte[readCount][], overallGCP = new byte[readCount][];
+        int r = 0;
+        for (final GATKSAMRecord read : processedReads) {
+            readBases[r] = read.getReadBases();
+            readQuals[r] = read.getBaseQualities();
+            insGOP[r] = read.getBaseInsertionQualities();
+            delGOP[r] = read.getBaseDeletionQualities();
+            overallGCP[r] = gcp.get(read);
+            r++;
+        }
+        final byte[][] hapBases = new byte[alleleCount][];
+        for (int a = 0; a < alleleCount; a++)
+            hapBases[a] = ((Allele) alleles.get(a)).getBases();
+        return new Ticket(jniSubmit(handle, readBases, readQuals, insGOP, delGOP, overallGCP, hapBases), likelihoods, readCount, alleleCount);
+    }
+
+    public void fetch(final Ticket ticket) {
+        mLikelihoodArray = new double[ticket.readCount * ticket.alleleCount];
+        jniFetch(handle, ticket.id, mLikelihoodArray);
+        int idx = 0;
+        for (int readIndex = 0; readIndex < ticket.readCount; readIndex++)
+            for (int a = 0; a < ticket.alleleCount; a++)
+                ticket.likelihoods.set(a, readIndex, mLikelihoodArray[idx++]);
+        initialized = true;
     }
 
     @Override

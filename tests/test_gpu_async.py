@@ -296,3 +296,41 @@ def test_multi_device_handle_takes_tickets(oracle):
         assert h.stats()["region_hits"] == 1
     finally:
         h.close()
+
+
+def test_region_sent_ahead_raw_is_found_by_the_reads_the_caller_processed_itself(oracle):
+    """The upstream likelihood engine caps a read's base qualities by its mapping quality and squashes the ones under
+    BASE_QUALITY_SCORE_THRESHOLD (PairHMM.java:54) between initialize(haplotypes, perSampleReadList, ...) and
+    computeLikelihoods.  A region sent ahead raw, with the mapping qualities and the squashing option, is the same
+    computation as the processed reads that are asked for: served from the region, equal to scoring them directly."""
+    region = synth.make_batch(40, 5, 100, 260, seed=17, mean_qual=21.0)
+    mapq = (np.arange(region.num_reads) % 5 * 12 + 8).astype(np.uint8)
+    processed = region.read_quals.copy()
+    for r in range(region.num_reads):
+        lo, hi = region.read_offsets[r], region.read_offsets[r + 1]
+        processed[lo:hi] = oracle.modify_read_qualities(region.read_quals[lo:hi], mapq[r], True)
+    assert (processed != region.read_quals).any()
+    raw = Batch(region.read_bases, region.read_quals, region.ins_gop, region.del_gop, None, region.read_offsets, region.hap_bases,
+                region.hap_offsets, mapq)
+    asked = Batch(region.read_bases, processed, region.ins_gop, region.del_gop, region.gcp, region.read_offsets, region.hap_bases, region.hap_offsets)
+    h = pairhmm.HipLoglessPairHMM(0)
+    try:
+        h.set_option("squash_base_quals", 1)
+        h.initialize_region_batches([raw], 200, 1000)
+        got = h.compute_batch(asked)
+        assert h.stats()["region_hits"] == 1
+        assert close_enough(got, ref(oracle, asked))
+        # a quality that differs after the treatment as well: not the same computation
+        other = processed.copy()
+        other[3] = 41
+        h.compute_batch(Batch(region.read_bases, other, region.ins_gop, region.del_gop, region.gcp, region.read_offsets, region.hap_bases, region.hap_offsets))
+        assert h.stats()["region_misses"] == 1
+        h.finalizeRegion()
+        # without the option the raw bytes are what counts: the processed reads are strangers
+        h.set_option("squash_base_quals", 0)
+        h.initialize_region_batches([Batch(region.read_bases, region.read_quals, region.ins_gop, region.del_gop, None, region.read_offsets,
+                                           region.hap_bases, region.hap_offsets)], 200, 1000)
+        assert close_enough(h.compute_batch(asked), ref(oracle, asked))
+        assert h.stats()["region_hits"] == 1 and h.stats()["region_misses"] == 2
+    finally:
+        h.close()

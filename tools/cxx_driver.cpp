@@ -1,9 +1,11 @@
 // Exercises the C++ host mirrors (include/gatk_pairhmm.hpp, include/gatk_smithwaterman.hpp) end to end on
 // GPU 0: the closed-form single-base answers, the read-major array, an error path, the BatchPairHMM
-// interface, the ReadLikelihoods steps on resident results, three Smith-Waterman cases and a multi-device instance.
+// interface, the region-level hook and submit / fetch, the ReadLikelihoods steps on resident results, three Smith-Waterman cases and a multi-device instance.
 // Prints "cxx_driver ok" and exits 0 when everything matches.
 #include <cmath>
 #include <cstdio>
+#include <map>
+#include <string>
 
 #include "gatk_pairhmm.hpp"
 #include "gatk_smithwaterman.hpp"
@@ -34,6 +36,27 @@ int main() {
         const auto res = hmm.batchGetResult();
         if (res.size() != 2 || std::fabs(res[0] - want[0]) > 1e-6 || std::fabs(res[1] - want[2]) > 1e-6) { std::printf("batch mismatch\n"); return 1; }
         hmm.finalizeRegion();
+        {
+            // the region-level hook: two samples sent ahead, then one computeLikelihoods call per sample (served from the
+            // region: the stats count the hits), and a call in two halves through submit / fetch
+            const std::vector<gatk::Bytes> alleles = {B("A"), B("C"), B("AC")};
+            const std::map<std::string, std::vector<gatk::Read>> perSample = {{"s1", {reads[0]}}, {"s2", {reads[1], reads[0]}}};
+            hmm.initialize(alleles, perSample, 4, 8);
+            gatk::LikelihoodMatrix s1(alleles, 1), s2(alleles, 2);
+            hmm.computeLikelihoods(s1, perSample.at("s1"), {{10}});
+            hmm.computeLikelihoods(s2, perSample.at("s2"), {{10}, {10}});
+            gatk_pairhmm_stats st{};
+            gatk_pairhmm_get_stats(hmm.handle(), &st);
+            hmm.finalizeRegion();
+            for (int a = 0; a < 3; ++a)
+                if (s1.get(a, 0) != m.get(a, 0) || s2.get(a, 0) != m.get(a, 1) || s2.get(a, 1) != m.get(a, 0)) { std::printf("region hook mismatch\n"); return 1; }
+            if (st.region_hits != 2) { std::printf("region hook: %lld hits\n", static_cast<long long>(st.region_hits)); return 1; }
+            gatk::LikelihoodMatrix later(alleles, 2);
+            auto ticket = hmm.submit(later, reads, {{10}, {10}});
+            hmm.fetch(*ticket);
+            for (int a = 0; a < 3; ++a)
+                if (later.get(a, 0) != m.get(a, 0) || later.get(a, 1) != m.get(a, 1)) { std::printf("submit / fetch mismatch\n"); return 1; }
+        }
         {
             // the steps behind the path on resident results: alleles A (reference), C, AC against reads A and C
             const std::vector<gatk::Bytes> alleles = {B("A"), B("C"), B("AC")};
