@@ -46,6 +46,51 @@ def test_two_row_closed_form(oracle):
         assert out[0, 0] == pytest.approx(want, abs=1e-12)
 
 
+def test_reference_outputs_loader_round_trip(oracle, tmp_path):
+    """The loader of the file the JDK-box kit produces (java/test/PinOracleTest.java), on a file written here in that
+    format from the oracle's own numbers: Java's spelling of -Infinity, every pair once, a missing pair refused."""
+    from golden_reference import load_reference_outputs
+    b, _, want_exact = load_case("ragged")
+    rc, approx = oracle.compute_likelihoods(b, oracle.ORIGINAL)
+    assert rc == 0
+    lines = []
+    for mode, arr in (("exact", want_exact), ("original", approx)):
+        for r in range(arr.shape[0]):
+            for a in range(arr.shape[1]):
+                v = arr[r, a]
+                lines.append(f"ragged {mode} {r} {a} {'-Infinity' if np.isneginf(v) else repr(float(v))}")
+    path = tmp_path / "reference_outputs.txt"
+    path.write_text("# comment\n" + "\n".join(lines) + "\n")
+    got = load_reference_outputs(str(path))
+    np.testing.assert_array_equal(got["ragged"]["exact"], want_exact)
+    np.testing.assert_array_equal(got["ragged"]["original"], approx)
+    path.write_text("\n".join(lines[:-1]) + "\n")
+    with pytest.raises(ValueError):
+        load_reference_outputs(str(path))
+    assert load_reference_outputs(str(tmp_path / "absent.txt")) is None
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_oracle_against_the_references_own_outputs(oracle, name):
+    """Once tests/golden/reference_outputs.txt exists (the reference's Java run on the golden inputs on a machine with a
+    JDK), the oracle is pinned end to end: its exact and approximate log10 passes restate the same Java statement by
+    statement (1e-10: Math.log10 / Math.pow against libm), and the linear-space pass agrees with the exact one."""
+    from golden_reference import load_reference_outputs
+    ref_out = load_reference_outputs()
+    if ref_out is None or name not in ref_out:
+        pytest.skip("tests/golden/reference_outputs.txt has not been produced yet (no JDK in this image): parity unpinned")
+    b, _, _ = load_case(name)
+    for mode, key, tol in ((oracle.EXACT, "exact", 1e-10), (oracle.ORIGINAL, "original", 1e-10), (oracle.LOGLESS, "exact", 1e-9)):
+        if key not in ref_out[name]:
+            continue
+        rc, got = oracle.compute_likelihoods(b, mode)
+        assert rc == 0
+        want = ref_out[name][key]
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin)
+        assert np.abs(got[fin] - want[fin]).max(initial=0.0) <= tol
+
+
 @pytest.mark.parametrize("name", CASE_NAMES)
 def test_golden_fixtures(oracle, name):
     b, want_logless, want_exact = load_case(name)
