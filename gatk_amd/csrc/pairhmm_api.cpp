@@ -357,6 +357,16 @@ int record_stage_in_event(gatk_pairhmm* h) {
     return GATK_PAIRHMM_OK;
 }
 
+// Weight of a region towards a part of a cut call: see compute_regions_single.
+constexpr int64_t kLongPairCells = 100000;
+int64_t pipeline_weight(const gatk_pairhmm_batch& b, int64_t ref_cells) {
+    if (b.num_reads <= 0 || b.num_haps <= 0) return 0;
+    const int64_t pairs = static_cast<int64_t>(b.num_reads) * b.num_haps;
+    if (ref_cells <= 0) return pairs;
+    const int64_t cells = static_cast<int64_t>(b.read_offsets[b.num_reads] - b.read_offsets[0]) * (b.hap_offsets[b.num_haps] - b.hap_offsets[0]);
+    return cells > pairs * kLongPairCells ? std::max(pairs, cells / ref_cells) : pairs;
+}
+
 // checked: the caller has run check_region on these regions already (under their own indices)
 #ifdef PAIRHMM_CALL_CLOCKS
 #define PLAN_CLOCK(i) plan_clock[i] = now_ms()
@@ -384,7 +394,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     R->last_timing = gatk_pairhmm_stats{};
 
     // ---- pass 1: sizes, rows per lane, wave-groups ------------------------------------------------
-    int64_t call_pairs = 0, total_reads = 0, total_haps = 0, total_read_bytes = 0, hap_pool_bytes = 0;
+    int64_t call_pairs = 0, total_reads = 0, total_haps = 0, total_read_bytes = 0, hap_pool_bytes = 0, call_cells = 0;
     for (int k = 0; k < num_regions; ++k) {
         const gatk_pairhmm_batch& b = regions[k];
         const int nr = b.num_reads, nh = nr == 0 ? 0 : b.num_haps;
@@ -394,6 +404,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         total_reads += nr;
         total_haps += nh;
         total_read_bytes += b.read_offsets[nr] - b.read_offsets[0];
+        call_cells += static_cast<int64_t>(b.read_offsets[nr] - b.read_offsets[0]) * (b.hap_offsets[nh] - b.hap_offsets[0]);
         for (int a = 0; a < nh; ++a) hap_pool_bytes += (b.hap_offsets[a + 1] - b.hap_offsets[a] + 15) & ~15;
     }
     if (call_pairs >= (int64_t{1} << 31) || total_read_bytes >= (int64_t{1} << 31) || hap_pool_bytes >= (int64_t{1} << 31))
@@ -449,8 +460,11 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     }
 
     // a call that does not fill the device for long: one rows-per-lane value for all of it
+    // (pairs count by their length here as they do where a call is cut into parts: see compute_regions_single)
+    const int64_t call_weight = h->pipeline_cells_per_pair > 0 && call_cells > call_pairs * kLongPairCells
+                                    ? std::max(call_pairs, call_cells / h->pipeline_cells_per_pair) : call_pairs;
     int call_k = h->force_rows_per_lane;
-    if (call_k == 0 && call_pairs > 0 && call_pairs < h->per_group_factor * static_cast<int64_t>(h->wave_slots)) {
+    if (call_k == 0 && call_pairs > 0 && call_weight < h->per_group_factor * static_cast<int64_t>(h->wave_slots)) {
         std::vector<RegionShape> shapes;
         shapes.reserve(num_regions);
         int longest = 1;
@@ -837,7 +851,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     // the next part of an overlapped call must wait for the copy, not for this part's kernels.
     h->stage_in_unrecorded = s;
     h->stage_in_record_due = true;
-    if (upload_bytes > h->kernel_upload_bytes)
+    if (upload_bytes > h->kernel_upload_bytes || h->in_cut_call)
         if (int rc = record_stage_in_event(h)) return rc;
     R->plan_ms = t_planned - t_begin;
     R->upload_ms = now_ms() - t_planned;
@@ -1269,20 +1283,24 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
         }
     CALL_CLOCK("checked");
     const RegionCallCount in_flight(h->device);
-    // A region with more pairs than a part holds is cut by read ranges (its pairs are independent,
+    // How much of a part a region takes: its pairs, and for a region of long reads against long haplotypes (more
+    // than kLongPairCells cells per pair; "pipeline_pairs" was measured on pairs of 50 to 90 thousand) its cells over
+    // "pipeline_cells_per_pair", so that such a call is cut into parts of about the same device time: the fp64 pair
+    // pass of one part, which long high-indel reads need, then runs beside the fp32 pass of the next.
+    const int64_t ref_cells = h->pipeline_cells_per_pair;
+    auto weight_of = [ref_cells](const gatk_pairhmm_batch& b) -> int64_t { return pipeline_weight(b, ref_cells); };
+    // A region worth more than a part holds is cut by read ranges (its pairs are independent,
     // PairHMM.java:217): the pieces share its haplotypes and write into consecutive rows of its array.
     std::vector<gatk_pairhmm_batch> pieces;
     std::vector<double*> piece_outs;
     if (h->pipeline_pairs > 0) {
         bool any_large = false;
         for (int k = 0; k < num_regions && !any_large; ++k)
-            any_large = regions[k].num_reads > 1 && regions[k].num_haps > 0 &&
-                        static_cast<int64_t>(regions[k].num_reads) * regions[k].num_haps >= 2 * h->pipeline_pairs;
+            any_large = regions[k].num_reads > 1 && regions[k].num_haps > 0 && weight_of(regions[k]) >= 2 * h->pipeline_pairs;
         if (any_large) {
             for (int k = 0; k < num_regions; ++k) {
                 const gatk_pairhmm_batch& b = regions[k];
-                const int64_t pairs = b.num_haps > 0 ? static_cast<int64_t>(b.num_reads) * b.num_haps : 0;
-                const int n_pieces = static_cast<int>(std::min<int64_t>(std::max<int64_t>(pairs / h->pipeline_pairs, 1), std::max(b.num_reads, 1)));
+                const int n_pieces = static_cast<int>(std::min<int64_t>(std::max<int64_t>(weight_of(b) / h->pipeline_pairs, 1), std::max(b.num_reads, 1)));
                 for (int q = 0; q < n_pieces; ++q) {
                     const int r0 = static_cast<int>(static_cast<int64_t>(b.num_reads) * q / n_pieces);
                     const int r1 = static_cast<int>(static_cast<int64_t>(b.num_reads) * (q + 1) / n_pieces);
@@ -1300,23 +1318,20 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
             num_regions = static_cast<int>(pieces.size());
         }
     }
-    // parts of about pipeline_pairs pairs, cut between regions; the first two are a quarter and a half of that,
-    // so that the device starts early (nothing overlaps the planning of the first part)
+    // parts of about pipeline_pairs (weighted) pairs, cut between regions; the first two are a quarter and a half of
+    // that, so that the device starts early (nothing overlaps the planning of the first part)
     std::vector<int> cuts{0};
     if (h->pipeline_pairs > 0) {
         int64_t acc = 0, total = 0, taken = 0;
-        for (int k = 0; k < num_regions; ++k)
-            if (regions[k].num_reads > 0 && regions[k].num_haps > 0) total += static_cast<int64_t>(regions[k].num_reads) * regions[k].num_haps;
+        for (int k = 0; k < num_regions; ++k) total += weight_of(regions[k]);
         // a call of less than two parts' worth is cut in two halves, down to pipeline_min_pairs each, so that
         // the planning of the second half and the copy back of the first hide behind kernels
         const int64_t part_pairs = in_flight.others > 0 ? h->pipeline_pairs
                                  : std::max(std::min(h->pipeline_min_pairs, h->pipeline_pairs), std::min(h->pipeline_pairs, total / 2));
         const bool ramp = h->pipeline_ramp && total >= 3 * part_pairs;
         for (int k = 0; k < num_regions; ++k) {
-            if (regions[k].num_reads > 0 && regions[k].num_haps > 0) {
-                const int64_t pairs = static_cast<int64_t>(regions[k].num_reads) * regions[k].num_haps;
-                acc += pairs; taken += pairs;
-            }
+            const int64_t w = weight_of(regions[k]);
+            acc += w; taken += w;
             const size_t part = cuts.size() - 1;
             const int64_t want = !ramp || part >= 2 ? part_pairs : part_pairs >> (2 - part);
             // no cut that leaves less than half a part behind it
@@ -1341,6 +1356,7 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
     // depth 3: the host plans part p + 2 without waiting for part p first, so that the device always has a
     // whole part queued behind the one it is working on
     const int depth = h->pipeline_depth >= 3 ? 3 : 2;
+    struct InCutCall { bool& flag; explicit InCutCall(bool& f) : flag(f) { flag = true; } ~InCutCall() { flag = false; } } in_cut_call(h->in_cut_call);
     gatk_pairhmm_stats total{};
     int rc = GATK_PAIRHMM_OK;
     const int parts = static_cast<int>(cuts.size()) - 1;
@@ -1800,6 +1816,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) try
     else if (n == "squash_base_quals") h->squash_base_quals = value != 0;
     else if (n == "do_not_use_tristate_correction") h->no_tristate_correction = value != 0;
     else if (n == "pipeline_pairs") h->pipeline_pairs = std::max<int64_t>(0, static_cast<int64_t>(value));
+    else if (n == "pipeline_cells_per_pair") h->pipeline_cells_per_pair = std::max<int64_t>(0, static_cast<int64_t>(value));
     else if (n == "pipeline_ramp") h->pipeline_ramp = value != 0;
     else if (n == "pipeline_depth") h->pipeline_depth = value >= 3 ? 3 : 2;
     else if (n == "pipeline_min_pairs") h->pipeline_min_pairs = std::max<int64_t>(1, static_cast<int64_t>(value));

@@ -301,12 +301,14 @@ struct gatk_pairhmm {
     hipStream_t stream2 = nullptr, stream3 = nullptr;
     int pipeline_depth = 3;  // parts of a cut call in flight or in planning at once (2 or 3)
     int64_t pipeline_pairs = 98304;  // pairs per part of such a call; 0: never split a call
+    int64_t pipeline_cells_per_pair = 80000;  // pairs of more than 100 000 cells count as cells / this towards a part of a cut call; 0: count pairs only
     int64_t pipeline_min_pairs = 12288;  // the halves of a call with less than two parts' worth of pairs are at least this large
     pairhmm_host::PinnedBuf stage_in, stage_out;  // pinned staging shared by every upload / download on this handle
     hipEvent_t stage_in_copied = nullptr;  // recorded behind the host-to-device copy out of stage_in
     bool stage_in_busy = false;
     hipStream_t stage_in_unrecorded = nullptr;  // stream of an upload whose event is still to be recorded
     bool stage_in_record_due = false;
+    bool in_cut_call = false;  // a call cut into overlapped parts is under way: the next part waits for an upload's copy, not for its kernels
     std::vector<double> likelihood_array;
     gatk_pairhmm_stats stats{};
     // BatchPairHMM queue: one single-read region per batchAdd

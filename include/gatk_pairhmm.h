@@ -235,6 +235,10 @@ int gatk_pairhmm_device_count(int32_t* count);
  *   "pipeline_pairs"      default 98304: a compute call with more pairs is cut, between regions and inside a
  *                         large region between reads, into parts of about that many pairs, and one part is
  *                         planned and copied while the kernels of the parts before it run; 0 = never cut.
+ *   "pipeline_cells_per_pair" default 80000: in that count a region of long reads against long haplotypes (more than
+ *                         100 000 cells per pair) stands for its cells divided by this instead of its pairs, so that
+ *                         such a call is cut into parts of about the same device time and the fp64 pair pass of
+ *                         one part runs beside the fp32 pass of the next; 0 = count pairs only.
  *   "pipeline_ramp"       default 1: the first two parts are a quarter and a half of that.
  *   "pipeline_depth"      default 3: parts of a cut call that are in flight or being planned at once, each with
  *                         buffers and a stream of its own; 2 makes the host wait for part p before it plans
