@@ -6,7 +6,8 @@
 // one big call against region-at-a-time calls and against calls of a few dozen regions on a default handle,
 // host-pointer calls against the resident path, a multi-device handle (three engines on GPU 0) against one engine
 // for calls of many regions, few regions and one region cut by read ranges, and eight threads whose one-region
-// calls are combined into shared passes.  Last, Smith-Waterman calls of random sizes (a handful of pairs, thousands of
+// calls are combined into shared passes, then ten threads on submit / fetch and the region-level hook with a failing
+// request among them.  Last, Smith-Waterman calls of random sizes (a handful of pairs, thousands of
 // them with a sequence pool large enough to go up launch by launch, weights on both sides of the packed cell form's
 // limits, alignments with more elements than come back with the first copy): an alignment's elements must add up to its
 // sequences.
@@ -249,6 +250,70 @@ int main(int argc, char** argv) {
             if (failed[t]) { std::printf("combined calls: thread %d failed\nFAILED\n", t); return 1; }
         const double d7 = worst_difference(all, combined);
         if (!(d7 <= 2e-3)) { std::printf("combined calls differ: %g\nFAILED\n", d7); return 1; }
+    }
+
+    // eight caller threads on submit / fetch with three regions in flight each, one of them submitting a request with a
+    // negative gap quality now and then (which must fail alone), while two more threads send regions ahead through the
+    // region-level hook in groups of up to five samples and ask for them sample by sample
+    {
+        constexpr int kThreads = 10;
+        auto tickets_out = outputs();
+        std::vector<int> failed(kThreads, 0);
+        std::vector<std::thread> threads;
+        std::vector<uint8_t> bad_bases = {'A', 'C', 'G', 'T'}, bad_quals = {30, 30, 30, 30}, bad_ins = {45, 200, 45, 45}, bad_hap = {'A', 'C', 'G', 'T', 'A'};
+        const int32_t bad_roff[2] = {0, 4}, bad_hoff[2] = {0, 5};
+        const gatk_pairhmm_batch bad{1, 1, bad_bases.data(), bad_quals.data(), bad_ins.data(), nullptr, nullptr, bad_roff, bad_hap.data(), bad_hoff, nullptr};
+        for (int t = 0; t < kThreads; ++t)
+            threads.emplace_back([&, t]() {
+                gatk_pairhmm* hc = nullptr;
+                if (gatk_pairhmm_create(0, &hc) != 0) { failed[t] = 1; return; }
+                if (t < 8) {
+                    std::vector<int64_t> ring;
+                    double bad_out = 0.0;
+                    for (int k = t; k < num_regions; k += kThreads) {
+                        if (ring.size() == 3) {
+                            if (gatk_pairhmm_fetch(hc, ring.front()) != 0) { std::printf("fetch: %s\n", gatk_pairhmm_last_error()); failed[t] = 1; }
+                            ring.erase(ring.begin());
+                        }
+                        if (t == 3 && (k / kThreads) % 7 == 0) {
+                            double* bo = &bad_out;
+                            int64_t tb = 0;
+                            if (gatk_pairhmm_submit(hc, 1, &bad, &bo, &tb) != 0 || gatk_pairhmm_fetch(hc, tb) != GATK_PAIRHMM_ILLEGAL_ARGUMENT) failed[t] = 1;
+                        }
+                        double* out = tickets_out[k].empty() ? nullptr : tickets_out[k].data();
+                        int64_t ticket = 0;
+                        if (gatk_pairhmm_submit(hc, 1, &batches[k], &out, &ticket) != 0) { std::printf("submit: %s\n", gatk_pairhmm_last_error()); failed[t] = 1; break; }
+                        ring.push_back(ticket);
+                    }
+                    // the last tickets of every other thread are left to close()
+                    if (t % 2 == 0) for (int64_t ticket : ring) if (gatk_pairhmm_fetch(hc, ticket) != 0) failed[t] = 1;
+                    if (t % 2 == 1) for (size_t i = 0; i + 1 < ring.size(); ++i) if (gatk_pairhmm_fetch(hc, ring[i]) != 0) failed[t] = 1;
+                } else {
+                    int k = t;
+                    while (k < num_regions) {
+                        std::vector<int> mine;
+                        for (int n = 1 + (k % 5); n > 0 && k < num_regions; --n, k += kThreads) mine.push_back(k);
+                        std::vector<gatk_pairhmm_batch> ahead;
+                        for (int r : mine) ahead.push_back(batches[r]);
+                        if (gatk_pairhmm_initialize_region(hc, static_cast<int32_t>(ahead.size()), ahead.data(), 1022, 16000) != 0) { std::printf("initialize_region: %s\n", gatk_pairhmm_last_error()); failed[t] = 1; break; }
+                        for (int r : mine)
+                            if (gatk_pairhmm_compute_likelihoods(hc, &batches[r], tickets_out[r].empty() ? nullptr : tickets_out[r].data()) != 0) failed[t] = 1;
+                        if (mine.size() % 2 == 0 && gatk_pairhmm_finalize_region(hc) != 0) failed[t] = 1;  // every other region is replaced without it
+                    }
+                }
+                if (gatk_pairhmm_close(hc) != 0) failed[t] = 1;
+            });
+        for (auto& th : threads) th.join();
+        for (int t = 0; t < kThreads; ++t)
+            if (failed[t]) { std::printf("submit / fetch / region hook: thread %d failed\nFAILED\n", t); return 1; }
+        // every other thread's last ticket was dropped at close: its array may hold anything, so compare the rest
+        for (int t = 1; t < 8; t += 2) {
+            int last = -1;
+            for (int k = t; k < num_regions; k += kThreads) last = k;
+            if (last >= 0) tickets_out[last] = all[last];
+        }
+        const double d8 = worst_difference(all, tickets_out);
+        if (!(d8 <= 2e-3)) { std::printf("submit / fetch / region hook differ: %g\nFAILED\n", d8); return 1; }
     }
 
     // the queueing interface and the single-pair call on the first region that has a read
