@@ -185,16 +185,17 @@ int choose_call_rows_per_lane(const std::vector<RegionShape>& shapes, int longes
 // device full: the value with the fewest modelled vector instructions per read, taking the group's other
 // reads to be as long as its longest (reads are packed longest first, so they are close) and a typical
 // haplotype length for the weight of the pipeline fill.  A table: the planner asks once per wave-group.
-int choose_group_rows_per_lane(int longest) {
-    static const std::array<uint8_t, kWave * kMaxRowsPerLane> table = [] {
-        std::array<uint8_t, kWave * kMaxRowsPerLane> t{};
-        for (int len = 1; len <= kWave * kMaxRowsPerLane - 2; ++len) {
-            const int min_k = (len + 1 + kWave) / kWave;
-            int best_k = kMaxRowsPerLane;
+// allowed: bit k set = k rows per lane may be chosen (a read too long for every allowed value takes the best of all).
+std::array<uint8_t, kWave * kMaxRowsPerLane> group_rows_table(uint32_t allowed) {
+    std::array<uint8_t, kWave * kMaxRowsPerLane> t{};
+    for (int len = 1; len <= kWave * kMaxRowsPerLane - 2; ++len) {
+        const int min_k = (len + 1 + kWave) / kWave;
+        for (int pass = 0; pass < 2 && t[len] == 0; ++pass) {
+            int best_k = 0;
             double best = std::numeric_limits<double>::infinity();
             for (int k : kRowsPerLaneChoices) {
-                if (k < min_k) continue;
-                if (k > 12 && best_k != kMaxRowsPerLane) break;  // more rows cost a wave per SIMD: only for long reads
+                if (k < min_k || (pass == 0 && !((allowed >> k) & 1u))) continue;
+                if (k > 12 && best_k != 0) break;  // more rows cost a wave per SIMD: only for long reads
                 const int lanes = (len + 1 + k) / k;
                 double cost = (5.0 * k + 6.0) * (400.0 + lanes) / (kWave / lanes);
                 if (k > 10) cost *= 1.03;  // the one-haplotype fp64 pass spills beyond 10 rows
@@ -203,8 +204,13 @@ int choose_group_rows_per_lane(int longest) {
             }
             t[len] = static_cast<uint8_t>(best_k);
         }
-        return t;
-    }();
+        if (t[len] == 0) t[len] = kMaxRowsPerLane;
+    }
+    return t;
+}
+
+int choose_group_rows_per_lane(int longest) {
+    static const std::array<uint8_t, kWave * kMaxRowsPerLane> table = group_rows_table(~0u);
     return table[longest];
 }
 
@@ -558,7 +564,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
         const int region_k = per_group ? 0 : choose_rows_per_lane(lens_desc, nh, mean_hap, call_pairs, call_k);
         size_t pos = 0;
         while (pos < order.size()) {
-            int K = per_group ? choose_group_rows_per_lane(lens_desc[pos]) : region_k;
+            int K = !per_group ? region_k : h->group_rows_table.empty() ? choose_group_rows_per_lane(lens_desc[pos]) : h->group_rows_table[lens_desc[pos]];
             // everything in double: from 10 rows per lane on the fp64 pass no longer fits the register file and
             // spills, so reads that fit 8 rows per lane (up to 510 bases) take 8
             if (h->force_fp64 && h->force_rows_per_lane == 0 && K > 8 && lens_desc[pos] + 2 <= 8 * kWave &&
@@ -660,7 +666,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             for (size_t j = bucket_first; j < i; ++j) {
                 const RegionPlan& rp = plans[by_cost[j]];
                 for (int a = 0; a < rp.nh;) {
-                    int64_t c = remaining / (2 * static_cast<int64_t>(h->wave_slots));
+                    int64_t c = remaining / (h->stream_run_divisor * static_cast<int64_t>(h->wave_slots));
                     c = std::max<int64_t>(1, std::min<int64_t>(c, std::min(h->max_stream_haps, kMaxStreamHaps)));
                     c = std::min<int64_t>(c, rp.nh - a);
                     StreamDesc d{};
@@ -1819,6 +1825,12 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) try
     else if (n == "pipeline_cells_per_pair") h->pipeline_cells_per_pair = std::max<int64_t>(0, static_cast<int64_t>(value));
     else if (n == "pipeline_ramp") h->pipeline_ramp = value != 0;
     else if (n == "pipeline_depth") h->pipeline_depth = value >= 3 ? 3 : 2;
+    else if (n == "stream_run_divisor") h->stream_run_divisor = std::max(1, static_cast<int>(value));
+    else if (n == "group_rows_allowed") {  // bit k: k rows per lane may be chosen per wave-group; 0: all
+        const uint32_t allowed = static_cast<uint32_t>(value);
+        h->group_rows_table.clear();
+        if (allowed) { const auto t = group_rows_table(allowed); h->group_rows_table.assign(t.begin(), t.end()); }
+    }
     else if (n == "pipeline_min_pairs") h->pipeline_min_pairs = std::max<int64_t>(1, static_cast<int64_t>(value));
     else if (n == "combine_calls") h->combine_calls = value != 0;
     else if (n == "per_group_factor") h->per_group_factor = std::max<int64_t>(1, static_cast<int64_t>(value));

@@ -44,6 +44,11 @@ namespace pairhmm_hip {
 // 5 termination, 6 tasks.
 #ifdef PAIRHMM_PHASE_CLOCKS
 __device__ unsigned long long g_phase_clocks[8];
+// One entry per wave of the stream pass, in order of completion: {start, end} on the constant 100 MHz counter,
+// rows per lane, and the hardware id word (which XCD, CU and SIMD the wave ran on).
+constexpr unsigned kWaveLogEntries = 1u << 18;
+__device__ unsigned g_wave_log_count;
+__device__ uint4 g_wave_log[kWaveLogEntries];
 // The shares are kept in registers and added to the counters once, when the work item is over: an atomic in the
 // middle of the item would stand in front of every later global load of the wave (they return in order).
 #define PHASE_BEGIN() long long phase_t0 = clock64(); long long phase_acc[6] = {0, 0, 0, 0, 0, 0}
@@ -939,11 +944,19 @@ __device__ __forceinline__ void run_stream(const DeviceBatch& B, const int task_
     static_assert(is_lut(MODE), "the stream pass reads emission terms from the table");
     PHASE_BEGIN();
     // ---- which wave-group and haplotype run? (wave-uniform) ------------------------------------------
-    int lo = 0, hi = B.num_stream_descs - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (B.stream_descs[mid].task_begin <= task_idx) lo = mid; else hi = mid - 1;
+    // The last descriptor that begins at or before this item, by a search that narrows 64-fold per round: every
+    // lane probes one descriptor, so tens of thousands of descriptors take three dependent loads where halving
+    // takes fifteen (a wave holds its slot through every one of them).
+    int lo = 0;
+    for (int n = B.num_stream_descs; n > 1;) {
+        const int stride = (n + kWave - 1) / kWave;
+        const bool at_or_before = lane * stride < n && B.stream_descs[lo + lane * stride].task_begin <= task_idx;
+        // descriptors are sorted: the lanes that answer yes are lane 0 (the invariant) and a run behind it
+        const int last = __popcll(__ballot(at_or_before)) - 1;
+        lo += last * stride;
+        n = n - last * stride < stride ? n - last * stride : stride;
     }
+    lo = __builtin_amdgcn_readfirstlane(lo);
     const StreamDesc sdesc = B.stream_descs[lo];
     const GroupDesc grp = B.groups[sdesc.group_begin + (task_idx - sdesc.task_begin)];
     const int fill = grp.fill;
@@ -1117,6 +1130,16 @@ __device__ __forceinline__ void run_stream(const DeviceBatch& B, const int task_
     PHASE_FLUSH();
 }
 
+// One work item per wave.  (Tried on MI355X and not kept: persistent waves that take their items from a device-wide
+// counter.  With one item per wave a slot stands empty for 9 to 30 us between a wave and its successor, and workgroups
+// are dealt to the eight XCDs in turn whatever their load, so residency is 88 % on the 4096 x 64 batch and 78 % on
+// HaplotypeCaller-shaped work; persistent waves hold 100 % until the last tenth of the launch and are 8 to 14 % slower
+// all the same: waves of equal priority issue oldest first, a persistent wave keeps its age, two waves fill a SIMD's
+// issue slots, and the youngest of three ran at 0.4 of its share; stepping every wave through the four issue
+// priorities, one step per haplotype, brought the launch back to the time of one item per wave, not below it.  Dealing
+// the items to the XCDs one by one instead of four by four changed nothing either: on uniform work the XCDs in the
+// middle of the package finish 15 to 35 % later than the outer ones, and a launch that keeps all of them busy to the
+// end takes as long as one whose fast XCDs idle for its last tenth: the device's power budget sets the rate.)
 template <int K, int MODE>
 __global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_stream(const DeviceBatch B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1133,6 +1156,12 @@ __global__ void __launch_bounds__(kWave* kWavesPerBlock) fwd_stream(const Device
         atomicAdd(&g_phase_clocks[4], (unsigned long long)(clock64() - life_c0));
         atomicAdd(&g_phase_clocks[7], (unsigned long long)(wall_clock64() - life_w0));
         atomicAdd(&g_phase_clocks[6], 1ull);
+        const unsigned slot = atomicAdd(&g_wave_log_count, 1u);
+        unsigned hw_id = 0, xcc_id = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        if (slot < kWaveLogEntries)
+            g_wave_log[slot] = make_uint4(static_cast<unsigned>(life_w0), static_cast<unsigned>(wall_clock64()), static_cast<unsigned>(K) | (xcc_id << 8), hw_id);
     }
 #endif
 }
@@ -1717,5 +1746,16 @@ extern "C" int gatk_pairhmm_debug_phase_clocks(unsigned long long* out, int rese
         e = hipMemcpyToSymbol(HIP_SYMBOL(pairhmm_hip::g_phase_clocks), zero, sizeof(zero));
     }
     return e == hipSuccess ? 0 : -1;
+}
+// Copies out up to `capacity` wave-log entries (4 words each) and empties the log; returns how many there were.
+extern "C" int gatk_pairhmm_debug_wave_log(unsigned* out, unsigned capacity) {
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(pairhmm_hip::g_wave_log_count), sizeof n) != hipSuccess) return -1;
+    n = n < pairhmm_hip::kWaveLogEntries ? n : pairhmm_hip::kWaveLogEntries;
+    n = n < capacity ? n : capacity;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(pairhmm_hip::g_wave_log), static_cast<size_t>(n) * 16) != hipSuccess) return -1;
+    const unsigned zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(pairhmm_hip::g_wave_log_count), &zero, sizeof zero) != hipSuccess) return -1;
+    return static_cast<int>(n);
 }
 #endif
