@@ -228,6 +228,10 @@ int gatk_pairhmm_device_count(int32_t* count);
  *                         -1 (default) = runs, except in a call with fewer pairs than two per wave slot of the
  *                         device, where no wave would get a run and the one-haplotype pass saves a kernel launch.
  *   "max_stream_haps"     longest run, 1..16.
+ *   "stream_run_divisor"  default 2: a run holds the work items still to hand out divided by this many times the
+ *                         device's wave slots, so that runs shorten towards the end of a launch.
+ *   "group_rows_allowed"  bit k set = k rows per lane may be chosen for a wave-group of a large call (fewer values in
+ *                         use = fewer, larger launches at lower lane use); 0 (default) = every value.
  *   "squash_base_quals"   1 = base qualities under 18 count as 6, see gatk_pairhmm_batch.
  *   "do_not_use_tristate_correction"  1 = PairHMM.doNotUseTristateCorrection() (PairHMM.java:83-84, "only used for
  *                         debugging purposes"): the prior of a mismatching base is the error probability itself, not
