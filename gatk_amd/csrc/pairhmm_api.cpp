@@ -1057,21 +1057,29 @@ int digest_counters(gatk_pairhmm* h, gatk_pairhmm_resident* R, const int32_t* co
     R->ev_pending.clear();
     R->last_timing = st;
     h->stats = st;
+    h->error_region = h->error_read = -1;
     if (counters[0] & 3) {
         // which read: the first one (in the call's read order) that had an input error of either kind
-        std::string where;
+        int region = -1, read_in_region = -1;
         if (counters[kErrorReadSlot] > 0) {
             const int read = 0x7fffffff - counters[kErrorReadSlot];
             int k = static_cast<int>(std::upper_bound(R->region_read_begin.begin(), R->region_read_begin.end(), read) - R->region_read_begin.begin()) - 1;
             while (k > 0 && R->region_reads[k] == 0) --k;  // regions without reads share their successor's first index
-            if (k >= 0 && k < R->num_regions)
-                where = " (region " + std::to_string(R->region_label_base + k) + (R->regions_are_pieces ? " of the call's read-range pieces" : "") +
-                        ", read " + std::to_string(read - R->region_read_begin[k]) + ")";
+            if (k >= 0 && k < R->num_regions) { region = R->region_label_base + k; read_in_region = read - R->region_read_begin[k]; }
         }
-        if (counters[0] & 1) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "insert quality, deletion quality or gcp cannot be less than 0 (byte >= 128)" + where);
-        return fail(GATK_PAIRHMM_INDEX_OUT_OF_BOUNDS, "base quality 255 is outside the 255-entry error-probability cache" + where);
+        return fail_input_error(h, (counters[0] & 1) ? GATK_PAIRHMM_ILLEGAL_ARGUMENT : GATK_PAIRHMM_INDEX_OUT_OF_BOUNDS, region, read_in_region, R->regions_are_pieces);
     }
     return GATK_PAIRHMM_OK;
+}
+
+int fail_input_error(gatk_pairhmm* h, int code, int region, int read, bool regions_are_pieces) {
+    h->error_region = region;
+    h->error_read = read;
+    std::string where;
+    if (region >= 0)
+        where = " (region " + std::to_string(region) + (regions_are_pieces ? " of the call's read-range pieces" : "") + ", read " + std::to_string(read) + ")";
+    if (code == GATK_PAIRHMM_ILLEGAL_ARGUMENT) return fail(code, "insert quality, deletion quality or gcp cannot be less than 0 (byte >= 128)" + where);
+    return fail(code, "base quality 255 is outside the 255-entry error-probability cache" + where);
 }
 
 int download_begin(gatk_pairhmm* h, gatk_pairhmm_resident* R, double* const* outs, PendingDownload& d) {
@@ -1299,6 +1307,8 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
     // PairHMM.java:217): the pieces share its haplotypes and write into consecutive rows of its array.
     std::vector<gatk_pairhmm_batch> pieces;
     std::vector<double*> piece_outs;
+    std::vector<std::pair<int, int>> piece_origin;  // the caller's region and the first of its reads a piece holds
+    h->error_region = h->error_read = -1;
     if (h->pipeline_pairs > 0) {
         bool any_large = false;
         for (int k = 0; k < num_regions && !any_large; ++k)
@@ -1315,6 +1325,7 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
                     if (b.read_offsets) piece.read_offsets = b.read_offsets + r0;  // offsets stay absolute
                     if (b.read_mapq) piece.read_mapq = b.read_mapq + r0;
                     pieces.push_back(piece);
+                    piece_origin.emplace_back(k, r0);
                     double* out = likelihoods ? likelihoods[k] : nullptr;
                     piece_outs.push_back(out ? out + static_cast<int64_t>(r0) * b.num_haps : nullptr);
                 }
@@ -1346,12 +1357,18 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
     }
     cuts.push_back(num_regions);
     const bool are_pieces = !pieces.empty();
-    for (gatk_pairhmm_resident* R : {&h->scratch, &h->scratch2, &h->scratch3}) { R->region_label_base = 0; R->regions_are_pieces = are_pieces; }
+    for (gatk_pairhmm_resident* R : {&h->scratch, &h->scratch2, &h->scratch3}) { R->region_label_base = 0; R->regions_are_pieces = false; }
+    // an input error found in a read-range piece is reported under the caller's own region and read index
+    auto in_callers_terms = [&](int rc) {
+        if (rc == GATK_PAIRHMM_OK || !are_pieces || h->error_region < 0 || h->error_region >= static_cast<int>(piece_origin.size())) return rc;
+        const std::pair<int, int> at = piece_origin[static_cast<size_t>(h->error_region)];
+        return fail_input_error(h, rc, at.first, at.second + h->error_read, false);
+    };
     if (cuts.size() <= 2) {
         if (int rc = plan_and_upload(h, &h->scratch, num_regions, regions, true)) return rc;
         if (h->scratch.total_pairs == 0) { h->stats = gatk_pairhmm_stats{}; return GATK_PAIRHMM_OK; }
         if (int rc = enqueue_compute(h, &h->scratch)) return rc;
-        return download_into(h, &h->scratch, likelihoods);
+        return in_callers_terms(download_into(h, &h->scratch, likelihoods));
     }
     // part p is planned and copied while the kernels of the parts before it run; its results are fetched
     // while the kernels of the parts behind it run
@@ -1406,7 +1423,7 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
             R->ev_pending.clear();
         }
         g_last_error = msg;
-        return rc;
+        return in_callers_terms(rc);
     }
     h->stats = total;
     return GATK_PAIRHMM_OK;
@@ -1483,7 +1500,7 @@ static int compute_regions_multi(gatk_pairhmm* h, int32_t num_regions, const gat
         return rc;
     }
     // pieces: whole regions, or read ranges of a region worth more than half a device's share
-    struct Piece { gatk_pairhmm_batch b; double* out; int64_t cells; };
+    struct Piece { gatk_pairhmm_batch b; double* out; int64_t cells; int region, first_read; };
     std::vector<Piece> pieces;
     pieces.reserve(static_cast<size_t>(num_regions) + 4 * n_dev);
     const int64_t share = std::max<int64_t>(total_cells / n_dev, 1);
@@ -1496,7 +1513,7 @@ static int compute_regions_multi(gatk_pairhmm* h, int32_t num_regions, const gat
             const int r0 = static_cast<int>(static_cast<int64_t>(b.num_reads) * q / n_pieces);
             const int r1 = static_cast<int>(static_cast<int64_t>(b.num_reads) * (q + 1) / n_pieces);
             if (r1 == r0) continue;
-            Piece pc{b, likelihoods[k] + static_cast<int64_t>(r0) * b.num_haps, 0};
+            Piece pc{b, likelihoods[k] + static_cast<int64_t>(r0) * b.num_haps, 0, k, r0};
             pc.b.num_reads = r1 - r0;
             pc.b.read_offsets = b.read_offsets + r0;  // offsets stay absolute
             if (b.read_mapq) pc.b.read_mapq = b.read_mapq + r0;
@@ -1520,13 +1537,18 @@ static int compute_regions_multi(gatk_pairhmm* h, int32_t num_regions, const gat
     struct Share {
         std::vector<gatk_pairhmm_batch> batches;
         std::vector<double*> outs;
+        std::vector<std::pair<int, int>> origin;  // the caller's region and the first of its reads each batch holds
         int rc = GATK_PAIRHMM_OK;
         std::string error;
     };
     std::vector<Share> shares(static_cast<size_t>(n_dev));
     for (int d = 0; d < n_dev; ++d) {
         std::sort(mine[d].begin(), mine[d].end());  // input order within a device: neighbouring read ranges stay neighbours
-        for (int i : mine[d]) { shares[d].batches.push_back(pieces[i].b); shares[d].outs.push_back(pieces[i].out); }
+        for (int i : mine[d]) {
+            shares[d].batches.push_back(pieces[i].b);
+            shares[d].outs.push_back(pieces[i].out);
+            shares[d].origin.emplace_back(pieces[i].region, pieces[i].first_read);
+        }
     }
     // Nothing may leave a share's job as an exception: on a worker thread it would end the process, and on this
     // thread it would unwind `shares` from under the workers that are still scoring into it.
@@ -1567,9 +1589,17 @@ static int compute_regions_multi(gatk_pairhmm* h, int32_t num_regions, const gat
                       total.main_stream_pass = st.main_stream_pass; total.main_fp64 = st.main_fp64; }
     }
     h->stats = total;
-    for (int d = 0; d < n_dev; ++d)
-        if (shares[d].rc != GATK_PAIRHMM_OK)
-            return fail(shares[d].rc, shares[d].error + " (device " + std::to_string(h->children[d]->device) + ")");
+    h->error_region = h->error_read = -1;
+    for (int d = 0; d < n_dev; ++d) {
+        if (shares[d].rc == GATK_PAIRHMM_OK) continue;
+        // an input error is reported under the caller's region and read index, not under the engine's share of them
+        const gatk_pairhmm* c = h->children[d];
+        if (c->error_region >= 0 && c->error_region < static_cast<int>(shares[d].origin.size())) {
+            const std::pair<int, int> at = shares[d].origin[static_cast<size_t>(c->error_region)];
+            return fail_input_error(h, shares[d].rc, at.first, at.second + c->error_read, false);
+        }
+        return fail(shares[d].rc, shares[d].error + " (device " + std::to_string(c->device) + ")");
+    }
     return GATK_PAIRHMM_OK;
 }
 

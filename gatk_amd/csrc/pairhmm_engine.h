@@ -313,6 +313,9 @@ struct gatk_pairhmm {
     bool stage_in_record_due = false;
     bool in_cut_call = false;  // a call cut into overlapped parts is under way: the next part waits for an upload's copy, not for its kernels
     std::vector<double> likelihood_array;
+    // where the last call's input error was, as indices into the region list the failing pass was given (-1: the call
+    // did not fail on a read's qualities): callers that cut or deal out regions translate them into the caller's own
+    int error_region = -1, error_read = -1;
     gatk_pairhmm_stats stats{};
     // BatchPairHMM queue: one single-read region per batchAdd
     struct Queued {
@@ -336,6 +339,9 @@ struct gatk_pairhmm {
 namespace pairhmm_host {
 
 double now_ms();
+// fails with the message of an input error found on the device (code: ILLEGAL_ARGUMENT for a negative gap quality,
+// INDEX_OUT_OF_BOUNDS for base quality 255) at read `read` of region `region`, and records the two in h
+int fail_input_error(gatk_pairhmm* h, int code, int region, int read, bool regions_are_pieces);
 int check_handle(gatk_pairhmm* h);
 // The resident interface, the allocation-free entry point and the stream getter work on one device: on a
 // multi-device handle they are served by the engine of the first device in the handle's list.

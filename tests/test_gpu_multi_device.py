@@ -106,7 +106,8 @@ def test_multi_device_handle_options_errors_and_single_pair(multi, oracle, hc_re
     # the reference's exception reaches the caller whichever engine met it
     bad = synth.make_batch(40, 6, 100, 300, seed=3)
     bad.gcp = bad.gcp.copy(); bad.gcp[11] = 200
-    with pytest.raises(pairhmm.IllegalArgumentException):
+    # ... under the caller's own region and read index, although the engine that met it held a share of the regions
+    with pytest.raises(pairhmm.IllegalArgumentException, match=r"\(region 60, read 0\)"):
         multi.compute_regions(regions[:60] + [bad] + regions[60:])
     with pytest.raises(pairhmm.IllegalArgumentException, match="region 3"):  # host-side checks name the caller's region index
         worse = synth.make_batch(4, 2, 20, 50, seed=3)
@@ -193,3 +194,16 @@ def test_distinct_devices_when_the_box_has_them(hmm, hc_regions):
         assert_same([t.fetch()[0] for t in tickets], hmm.compute_regions(regions[:2 * n]))
     finally:
         h.close()
+
+
+def test_an_error_in_a_region_cut_by_read_ranges_names_the_callers_read(multi, hmm):
+    """A region large enough to be cut by read ranges, on one engine (parts of a cut call) and over several (one range
+    per engine): a base quality of 255 deep inside it is reported as read 3000 of region 1, not as a read of a piece."""
+    big = synth.make_batch(4096, 64, 151, 600, seed=21)
+    big.read_quals = big.read_quals.copy()
+    big.read_quals[int(big.read_offsets[3000]) + 5] = 255
+    small = synth.make_batch(6, 3, 50, 120, seed=2)
+    for engine in (hmm, multi):
+        with pytest.raises(pairhmm.ArrayIndexOutOfBoundsException, match=r"\(region 1, read 3000\)"):
+            engine.compute_regions([small, big])
+        assert np.isfinite(engine.compute_regions([small])[0]).all()

@@ -238,6 +238,26 @@ def test_zero_length_read_and_empty_batch(hmm, oracle):
     assert hmm.compute_batch(empty).shape == (0, 1)
 
 
+def test_staging_buffer_that_has_to_grow_while_the_read_copies_run(oracle):
+    """The staging buffer is sized from the call's reads, haplotypes and regions before the per-base arrays are copied
+    into it; the output slots of zero-length reads are listed in it as well, and thousands of them against a hundred
+    haplotypes outgrow that size on a fresh handle: the buffer moves with the read arrays already in it.  Every
+    ordinary read's likelihoods must come out as from a call of their own."""
+    h = pairhmm.HipLoglessPairHMM(0)
+    try:
+        front = synth.make_batch(20, 4, 80, 200, seed=5)
+        mixed = synth.make_batch(6, 100, 60, 150, seed=6)
+        lens = np.concatenate([np.diff(mixed.read_offsets), np.zeros(4000, dtype=np.int64)])
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        many_empty = Batch(mixed.read_bases, mixed.read_quals, mixed.ins_gop, mixed.del_gop, mixed.gcp, offsets, mixed.hap_bases, mixed.hap_offsets)
+        got = h.compute_regions([front, many_empty])
+        assert_parity(got[0], ref(oracle, front))
+        assert_parity(got[1][:6], ref(oracle, mixed))
+        assert got[1].shape == (4006, 100) and np.isneginf(got[1][6:]).all()
+    finally:
+        h.close()
+
+
 def test_error_conventions(hmm):
     ok = ("ACGT", [30] * 4, [45] * 4, [45] * 4, [10] * 4)
     for k in (2, 3, 4):  # negative Java byte in ins / del / gcp (PairHMMModel.java:136-138)
