@@ -277,6 +277,32 @@ __device__ __forceinline__ void column(Rows<T, K>& w, const T (&prior)[K], const
     w.Iout = Iup;
 }
 
+// The scaled column of the stream pass.  The diagonal term of a lane's first row is the hand-off Sn that the lane
+// above made two steps earlier; column() has it fetched one step ahead into Sd[0] (a DPP move of its own) and
+// multiplies a step later.  Here the lane above keeps that hand-off for one more step (Sheld), and the multiply of the
+// first row reads it through DPP itself: one vector instruction less per step.  Sd0 is the value to multiply with
+// (the caller passes shr1(w.Sheld), or 0 for a lane at a gap); Sd[0] is not used.
+template <int K>
+__device__ __forceinline__ void column_stream(Rows<float, K>& w, float& Sheld, const float (&prior)[K], const float Sd0, const float Iin) {
+    float Iup = Iin;
+    float Snext = 0.0f;
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        const float M = prior[r] * (r == 0 ? Sd0 : w.Sd[r]);
+        const float E = fma_(w.El[r], w.T5[r], w.Ml[r]);
+        const float In = fma_(Iup, w.A[r], M);
+        const float Sn = fma_(E, w.C[r], fma_(Iup, w.B[r], M));
+        w.Ml[r] = M;
+        w.El[r] = E;
+        if (r > 0) w.Sd[r] = Snext;
+        Snext = Sn;
+        Iup = In;
+    }
+    Sheld = w.Sout;  // the hand-off of the step before this one: what the lane below multiplies with in its next step
+    w.Sout = Snext;
+    w.Iout = Iup;
+}
+
 // The column for loops whose steps alternate PARITY 0, 1, 0, 1 ... and run under a lane mask (a lane outside its
 // haplotype skips the column).  Under a mask every new state value that cannot take the register of the old one costs a
 // copy at the end of the masked block, and the deletion term E = E' * t5 + M' is an FMA whose addend is the old M: the
@@ -1026,6 +1052,7 @@ __device__ __forceinline__ void run_stream(const DeviceBatch& B, const int task_
         }
         w.Sout = 0.0f; w.Iout = 0.0f;
     }
+    float sheld = 0.0f;  // see column_stream
     // pad rows of this lane: rows [0, num_pad)
     const int num_pad = used ? (1 - ld.first_row < 0 ? 0 : (1 - ld.first_row > K ? K : 1 - ld.first_row)) : 0;
     __builtin_amdgcn_wave_barrier();
@@ -1037,11 +1064,18 @@ __device__ __forceinline__ void run_stream(const DeviceBatch& B, const int task_
     const uint16_t* const hp = B.hap_stream + run_base - t;  // hp[s]: table offset of this lane's position at step s
     const unsigned char* const tbl_lane = slice + lane * 4 * kLutRowsPerRead;
     auto emit = [&](const unsigned code_off, T (&prior)[K]) { lut_emit<T, K, kCodes>(tbl_lane, code_off, prior); };
+    // The table position of a step is the lane's table base plus the base code's offset, one of a packed pair of
+    // 16-bit offsets: added as 32-bit LDS addresses, the unpacking folds into the add (v_add_u32 with a 16-bit
+    // operand select) instead of costing an instruction of its own.
+    const unsigned tbl_lane_lds = static_cast<unsigned>(reinterpret_cast<size_t>((const __attribute__((address_space(3))) unsigned char*)tbl_lane));
+    auto table_at = [](const unsigned lds_addr) {
+        return (const unsigned char*)reinterpret_cast<const __attribute__((address_space(3))) unsigned char*>(static_cast<size_t>(lds_addr));
+    };
     auto emit4 = [&](const uint2 codes, T (&prior)[4][K]) {
-        emit(codes.x & 0xffffu, prior[0]);
-        emit(codes.x >> 16, prior[1]);
-        emit(codes.y & 0xffffu, prior[2]);
-        emit(codes.y >> 16, prior[3]);
+        lut_emit<T, K, kCodes>(table_at(tbl_lane_lds + (codes.x & 0xffffu)), 0u, prior[0]);
+        lut_emit<T, K, kCodes>(table_at(tbl_lane_lds + (codes.x >> 16)), 0u, prior[1]);
+        lut_emit<T, K, kCodes>(table_at(tbl_lane_lds + (codes.y & 0xffffu)), 0u, prior[2]);
+        lut_emit<T, K, kCodes>(table_at(tbl_lane_lds + (codes.y >> 16)), 0u, prior[3]);
     };
     StreamLane sl{0, 0, __int_as_float(gaps[0].y)};
     // One step of a block in which some lane is at a gap.  A lane at a gap hands in the finished
@@ -1050,17 +1084,18 @@ __device__ __forceinline__ void run_stream(const DeviceBatch& B, const int task_
     // next haplotype (M = I = 0, D as initialised, hand-offs to the right and downwards included),
     // whatever base code the gap entry holds.  Lanes outside the run compute on, unobserved.
     auto masked_step = [&](const int step, const unsigned code_off) {
-        const T Sin = shr1(w.Sout);
+        T Sd0 = shr1(sheld);
         T Iin = shr1(w.Iout);
         if (step - t == sl.next_gap) {
             if (sl.gap_idx > 0 && ld.seg_last != 0 && used)
-                B.raw_out[out_base + sl.gap_idx - 1] = w.El[K - 1] + w.Ml[K - 1] + w.Sd[K - 1];  // the sum row
+                B.raw_out[out_base + sl.gap_idx - 1] = w.El[K - 1] + w.Ml[K - 1] + (K == 1 ? Sd0 : w.Sd[K - 1]);  // the sum row
 #pragma unroll
             for (int r = 0; r < K; ++r) {
                 w.Ml[r] = 0.0f;
                 w.El[r] = r < num_pad ? sl.init_d : 0.0f;
                 w.Sd[r] = 0.0f;
             }
+            Sd0 = 0.0f;
             Iin = 0.0f;
             const int2 next = gaps[sl.gap_idx + 1];
             sl.next_gap = next.x;
@@ -1069,7 +1104,7 @@ __device__ __forceinline__ void run_stream(const DeviceBatch& B, const int task_
         }
         T prior[K];
         emit(code_off, prior);
-        column<T, K>(w, prior, Sin, Iin);
+        column_stream<K>(w, sheld, prior, Sd0, Iin);
     };
 
     const int num_blocks = (run_end + fill + 4) >> 2;  // steps 0 .. run_end + fill
@@ -1106,9 +1141,8 @@ __device__ __forceinline__ void run_stream(const DeviceBatch& B, const int task_
                 emit4(codes, pn);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const T Sin = shr1(w.Sout);
                     const T Iin = shr1(w.Iout);
-                    column<T, K>(w, pc[u], Sin, Iin);
+                    column_stream<K>(w, sheld, pc[u], shr1(sheld), Iin);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
