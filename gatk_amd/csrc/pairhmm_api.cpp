@@ -1863,7 +1863,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) try
     }
     else if (n == "pipeline_min_pairs") h->pipeline_min_pairs = std::max<int64_t>(1, static_cast<int64_t>(value));
     else if (n == "combine_calls") h->combine_calls = value != 0;
-    else if (n == "per_group_factor") h->per_group_factor = std::max<int64_t>(1, static_cast<int64_t>(value));
+    else if (n == "per_group_factor") h->per_group_factor = std::max<int64_t>(0, static_cast<int64_t>(value));  // 0: every call chooses per wave-group
     else if (n == "kernel_download_bytes") h->kernel_download_bytes = static_cast<size_t>(std::max(0.0, value));
     else if (n == "signal_download_bytes") h->signal_download_bytes = static_cast<size_t>(std::max(0.0, value));
     else if (n == "kernel_upload_bytes") h->kernel_upload_bytes = static_cast<size_t>(std::max(0.0, value));

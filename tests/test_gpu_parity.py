@@ -587,7 +587,8 @@ def test_extreme_gap_quality_steps(hmm, oracle):
 # ---- haplotype runs (the fp32 stream pass) ------------------------------------------------------
 
 def with_options(hmm, opts, fn):
-    defaults = {"stream_mode": 1, "max_stream_haps": 16, "force_rows_per_lane": 0, "emit_mode": -1, "force_fp64": 0}  # the session handle's
+    defaults = {"stream_mode": 1, "max_stream_haps": 16, "force_rows_per_lane": 0, "emit_mode": -1, "force_fp64": 0,
+                "stream_run_divisor": 2, "group_rows_allowed": 0, "per_group_factor": 32}  # the session handle's
     for k, v in opts.items():
         hmm.set_option(k, v)
     try:
@@ -768,7 +769,11 @@ def test_random_shapes_and_options(hmm, oracle, seed):
         regions.append(b)
     opts = {"stream_mode": int(rng.choice([1, 1, 0, -1])), "max_stream_haps": int(rng.choice([1, 3, 16])),
             "emit_mode": int(rng.choice([-1, -1, 0]))}
-    if rng.random() < 0.4:
+    opts["stream_run_divisor"] = int(rng.choice([2, 2, 1, 7]))
+    if rng.random() < 0.3:  # rows per lane chosen per wave-group as in a large call, from every value or from a few
+        opts["per_group_factor"] = 0
+        opts["group_rows_allowed"] = int(rng.choice([0, (1 << 9) | (1 << 10), 1 << 16, 1 << 3, (1 << 5) | (1 << 12)]))
+    elif rng.random() < 0.4:
         longest = max(int(np.diff(b.read_offsets).max()) for b in regions)
         ks = [k for k in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16) if 64 * k >= longest + 2]
         opts["force_rows_per_lane"] = int(rng.choice(ks))
