@@ -10,6 +10,9 @@
 #if __has_include(<jni.h>)
 #include <jni.h>
 
+#include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -55,6 +58,10 @@ struct PendingResult {
     int64_t ticket = 0;
     std::vector<double> values;
 };
+
+// The results of a handle's tickets that have not been fetched yet: jniClose frees what the Java side never asked for.
+std::mutex g_pending_mutex;
+std::map<gatk_pairhmm*, std::set<PendingResult*>> g_pending;
 
 // PairHMM.java:276-279: every per-read array must be as long as the read's bases.  The Java class checks this
 // too; a caller that reaches the native method some other way gets the same exception instead of misaligned bytes.
@@ -188,11 +195,20 @@ JNIEXPORT jlong JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPai
     pending->values.assign(static_cast<size_t>(b.num_reads) * static_cast<size_t>(b.num_haps), 0.0);
     double* out = pending->values.data();
     if (const int rc = gatk_pairhmm_submit(H(h), 1, &b, &out, &pending->ticket)) { delete pending; throw_for(env, rc); return 0; }
+    {
+        std::lock_guard<std::mutex> lock(g_pending_mutex);
+        g_pending[H(h)].insert(pending);
+    }
     return reinterpret_cast<jlong>(pending);
 }
 
 JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniFetch(JNIEnv* env, jclass, jlong h, jlong ticket, jdoubleArray likelihoodArray) {
     PendingResult* pending = reinterpret_cast<PendingResult*>(ticket);
+    {   // a ticket of this handle that has not been fetched before, or nothing is touched
+        std::lock_guard<std::mutex> lock(g_pending_mutex);
+        const auto of_handle = g_pending.find(H(h));
+        if (!pending || of_handle == g_pending.end() || of_handle->second.erase(pending) == 0) pending = nullptr;
+    }
     if (!pending) { env->ThrowNew(env->FindClass("java/lang/IllegalArgumentException"), "no such ticket"); return; }
     const int rc = gatk_pairhmm_fetch(H(h), pending->ticket);
     if (rc) throw_for(env, rc);
@@ -223,7 +239,14 @@ JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPair
 }
 
 JNIEXPORT void JNICALL Java_org_broadinstitute_gatk_utils_pairhmm_HipLoglessPairHMM_jniClose(JNIEnv*, jclass, jlong h) {
-    gatk_pairhmm_close(H(h));
+    gatk_pairhmm_close(H(h));  // waits for the passes that still write into unfetched results, then drops their tickets
+    std::set<PendingResult*> unfetched;
+    {
+        std::lock_guard<std::mutex> lock(g_pending_mutex);
+        const auto of_handle = g_pending.find(H(h));
+        if (of_handle != g_pending.end()) { unfetched.swap(of_handle->second); g_pending.erase(of_handle); }
+    }
+    for (PendingResult* p : unfetched) delete p;
 }
 
 // ---- HipResidentReadLikelihoods: the ReadLikelihoods steps on results that stay on the device ------------------------
