@@ -1346,13 +1346,19 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
         const int64_t part_pairs = in_flight.others > 0 ? h->pipeline_pairs
                                  : std::max(std::min(h->pipeline_min_pairs, h->pipeline_pairs), std::min(h->pipeline_pairs, total / 2));
         const bool ramp = h->pipeline_ramp && total >= 3 * part_pairs;
+        // A call of less than three parts' worth that has the device to itself is cut in four, an eighth, a quarter and
+        // twice five sixteenths of it: the device starts after the planning of an eighth, and each part's planning and
+        // copy back hide behind the kernels of its neighbours.  (Against two halves, on 64 / 128 / 192 / 256 / 320
+        // HaplotypeCaller-sized regions per call: 3 / 9 / 7 / 16 / 13 % less time.)
+        const bool mid_ramp = h->pipeline_ramp && !ramp && in_flight.others == 0 && total >= 8 * h->pipeline_mid_ramp_min;
         for (int k = 0; k < num_regions; ++k) {
             const int64_t w = weight_of(regions[k]);
             acc += w; taken += w;
             const size_t part = cuts.size() - 1;
-            const int64_t want = !ramp || part >= 2 ? part_pairs : part_pairs >> (2 - part);
+            const int64_t want = mid_ramp ? (part == 0 ? total / 8 : part == 1 ? total / 4 : 5 * total / 16)
+                                          : !ramp || part >= 2 ? part_pairs : part_pairs >> (2 - part);
             // no cut that leaves less than half a part behind it
-            if (acc >= want && k + 1 < num_regions && 2 * (total - taken) >= part_pairs) { cuts.push_back(k + 1); acc = 0; }
+            if (acc >= want && k + 1 < num_regions && 2 * (total - taken) >= (mid_ramp ? want : part_pairs)) { cuts.push_back(k + 1); acc = 0; }
         }
     }
     cuts.push_back(num_regions);
@@ -1855,6 +1861,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) try
     else if (n == "pipeline_cells_per_pair") h->pipeline_cells_per_pair = std::max<int64_t>(0, static_cast<int64_t>(value));
     else if (n == "pipeline_ramp") h->pipeline_ramp = value != 0;
     else if (n == "pipeline_depth") h->pipeline_depth = value >= 3 ? 3 : 2;
+    else if (n == "pipeline_mid_ramp_min") h->pipeline_mid_ramp_min = static_cast<int64_t>(value);
     else if (n == "stream_run_divisor") h->stream_run_divisor = std::max(1, static_cast<int>(value));
     else if (n == "group_rows_allowed") {  // bit k: k rows per lane may be chosen per wave-group; 0: all
         const uint32_t allowed = static_cast<uint32_t>(value);

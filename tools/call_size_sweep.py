@@ -17,7 +17,7 @@ options = [(a.split("=")[0], float(a.split("=")[1])) for a in sys.argv[1:] if "=
 regions = synth.make_regions(2000, seed=5)
 lib = pairhmm.load_library()
 print("options:", options or "defaults")
-for n in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1000, 2000):
+for n in [int(x) for x in os.environ.get("SWEEP_SIZES", "1,2,4,8,16,32,64,128,256,512,1000,2000").split(",")]:
     g = regions[:n]
     pairs = sum(b.num_reads * b.num_haps for b in g)
     cells = sum(int(np.diff(b.read_offsets).sum()) * int(np.diff(b.hap_offsets).sum()) for b in g)
