@@ -1335,7 +1335,7 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
             num_regions = static_cast<int>(pieces.size());
         }
     }
-    // parts of about pipeline_pairs (weighted) pairs, cut between regions; the first two are a quarter and a half of
+    // parts of about pipeline_pairs (weighted) pairs, cut between regions; the first three are an eighth, a quarter and a half of
     // that, so that the device starts early (nothing overlaps the planning of the first part)
     std::vector<int> cuts{0};
     if (h->pipeline_pairs > 0) {
@@ -1356,7 +1356,7 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
             acc += w; taken += w;
             const size_t part = cuts.size() - 1;
             const int64_t want = mid_ramp ? (part == 0 ? total / 8 : part == 1 ? total / 4 : 5 * total / 16)
-                                          : !ramp || part >= 2 ? part_pairs : part_pairs >> (2 - part);
+                                          : !ramp || static_cast<int>(part) >= h->pipeline_ramp_steps ? part_pairs : part_pairs >> (h->pipeline_ramp_steps - static_cast<int>(part));
             // no cut that leaves less than half a part behind it
             if (acc >= want && k + 1 < num_regions && 2 * (total - taken) >= (mid_ramp ? want : part_pairs)) { cuts.push_back(k + 1); acc = 0; }
         }
@@ -1861,6 +1861,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) try
     else if (n == "pipeline_cells_per_pair") h->pipeline_cells_per_pair = std::max<int64_t>(0, static_cast<int64_t>(value));
     else if (n == "pipeline_ramp") h->pipeline_ramp = value != 0;
     else if (n == "pipeline_depth") h->pipeline_depth = value >= 3 ? 3 : 2;
+    else if (n == "pipeline_ramp_steps") h->pipeline_ramp_steps = std::max(0, std::min(4, static_cast<int>(value)));
     else if (n == "pipeline_mid_ramp_min") h->pipeline_mid_ramp_min = static_cast<int64_t>(value);
     else if (n == "stream_run_divisor") h->stream_run_divisor = std::max(1, static_cast<int>(value));
     else if (n == "group_rows_allowed") {  // bit k: k rows per lane may be chosen per wave-group; 0: all

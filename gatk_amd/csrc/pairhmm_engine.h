@@ -284,6 +284,7 @@ struct gatk_pairhmm {
     int64_t per_group_factor = 32;  // calls with at least this many pairs per wave slot choose rows per lane per wave-group
     bool combine_calls = false;  // small compute_likelihoods calls of all threads on this device share the device's dispatcher
     int64_t pipeline_mid_ramp_min = 3840;  // a call of at least eight times this many pairs (and less than three parts' worth) is cut in four
+    int pipeline_ramp_steps = 3;  // parts of a large cut call that come before the first full one, each half the size of the next
     bool pipeline_ramp = true;  // the first two parts of a cut call are a quarter and a half of pipeline_pairs
     int stream_lds_floor = 0;  // least LDS bytes per wave of the stream pass (caps the waves a CU holds)
     double* d_err = nullptr;

@@ -243,7 +243,9 @@ int gatk_pairhmm_device_count(int32_t* count);
  *                         100 000 cells per pair) stands for its cells divided by this instead of its pairs, so that
  *                         such a call is cut into parts of about the same device time and the fp64 pair pass of
  *                         one part runs beside the fp32 pass of the next; 0 = count pairs only.
- *   "pipeline_ramp"       default 1: the first two parts are a quarter and a half of that.
+ *   "pipeline_ramp"       default 1: the first parts are smaller, so that the device starts early: "pipeline_ramp_steps"
+ *                         (default 3) parts of an eighth, a quarter and a half of a full part; a call of 30 000 pairs to
+ *                         three parts' worth is cut in four parts of 1/8, 1/4, 5/16 and 5/16 of its pairs.
  *   "pipeline_depth"      default 3: parts of a cut call that are in flight or being planned at once, each with
  *                         buffers and a stream of its own; 2 makes the host wait for part p before it plans
  *                         part p + 2.
