@@ -43,7 +43,7 @@ PEAK_FP64_VALU_TFLOPS = 78.6   # the fp64 passes: half the fp32 vector rate
 # HBM bytes of one fp32 forward launch on the default workload, from PMC counters collected in a run
 # of their own (2 x FETCH_SIZE + WRITE_SIZE); not measured live
 # (FETCH_SIZE counts a wide coalesced read at half its bytes on gfx950: doubled; both counters are in KiB)
-PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD = (2 * 10274.9 + 6442.8) * 1024
+PMC_TRAFFIC_BYTES_DEFAULT_WORKLOAD = (2 * 10285.2 + 6588.8) * 1024
 PMC_TRAFFIC_SOURCE = "profiles/r03_pmc_stream_kernel.txt (separate rocprofv3 --pmc passes over tools/prof_run.py 4096 4; not measured in this run)"
 EMIT_MODES = {0: "compare", 1: "compare+N", 2: "table", 3: "table+N"}
 
