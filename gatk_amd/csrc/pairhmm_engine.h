@@ -307,7 +307,7 @@ struct gatk_pairhmm {
     int pipeline_depth = 3;  // parts of a cut call in flight or in planning at once (2 or 3)
     int64_t pipeline_pairs = 98304;  // pairs per part of such a call; 0: never split a call
     int64_t pipeline_cells_per_pair = 80000;  // pairs of more than 100 000 cells count as cells / this towards a part of a cut call; 0: count pairs only
-    int64_t pipeline_min_pairs = 12288;  // the halves of a call with less than two parts' worth of pairs are at least this large
+    int64_t pipeline_min_pairs = 6144;  // the halves of a call with less than two parts' worth of pairs are at least this large
     pairhmm_host::PinnedBuf stage_in, stage_out;  // pinned staging shared by every upload / download on this handle
     hipEvent_t stage_in_copied = nullptr;  // recorded behind the host-to-device copy out of stage_in
     bool stage_in_busy = false;

@@ -249,7 +249,7 @@ int gatk_pairhmm_device_count(int32_t* count);
  *   "pipeline_depth"      default 3: parts of a cut call that are in flight or being planned at once, each with
  *                         buffers and a stream of its own; 2 makes the host wait for part p before it plans
  *                         part p + 2.
- *   "pipeline_min_pairs"  default 12288: a compute_regions call of less than two parts' worth of pairs that has
+ *   "pipeline_min_pairs"  default 6144: a compute_regions call of less than two parts' worth of pairs that has
  *                         the device to itself is cut in two halves of at least this many pairs, so that
  *                         planning the second and fetching the first hide behind kernels.
  *   "per_group_factor"    default 32: a call, or a part of a cut call, with fewer pairs than this many per wave

@@ -901,10 +901,11 @@ def test_small_results_come_home_the_same_through_flag_event_and_copy():
         h.close()
 
 
-@pytest.mark.parametrize("num_regions", [10, 40, 70])
+@pytest.mark.parametrize("num_regions", [10, 25, 40, 70, 150])
 def test_mid_sized_calls_on_a_default_handle(oracle, num_regions):
-    """Calls of some thousand to some ten thousand pairs on a handle with default options: one rows-per-lane
-    value for the whole call, and from about 18 000 pairs on two overlapped halves.  Regions with reads of different
+    """Calls of some thousand to a hundred thousand pairs on a handle with default options: one rows-per-lane
+    value for the whole call, from about 12 000 pairs on two overlapped halves, from about 30 000 on four growing
+    parts.  Regions with reads of different
     lengths, an empty region and a zero-length read among them; same results as with one region per call."""
     regions = synth.make_regions(num_regions, seed=300 + num_regions, coverage=30, read_len=151)
     regions += synth.make_regions(3, seed=17, coverage=10, read_len=60)
