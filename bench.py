@@ -105,8 +105,12 @@ def cpu_baseline(batch, target_seconds=8.0):
     def scalar(b):
         assert O.compute_likelihoods(b, O.LOGLESS, fast_threads=threads)[0] == 0
 
+    def scalar_one_thread(b):
+        assert O.compute_likelihoods(b, O.LOGLESS, fast_threads=1)[0] == 0
+
     s1, n1, dt1, reps1 = timed_sample(simd, batch, threads, target_seconds)
     s2, n2, dt2, reps2 = timed_sample(scalar, batch, threads, target_seconds)
+    s3, n3, dt3, reps3 = timed_sample(scalar_one_thread, batch, 1, target_seconds / 2)
     return {"value": round(s1.cells / dt1 / 1e9, 3), "unit": "GCUPS", "cores": threads, "kind": "port",
             "host": {"cpu": cpu_model(), "os_cpu_count": os.cpu_count(), "cpus_in_affinity_mask": allowed, "OMP_NUM_THREADS": omp,
                      "threads_used": threads,
@@ -114,7 +118,9 @@ def cpu_baseline(batch, target_seconds=8.0):
             "sample": f"first {n1} of {batch.num_reads} reads x {batch.num_haps} haplotypes of the same batch ({s1.cells:.3e} cells, "
                       f"{reps1} x {dt1:.2f} s), fp32 with fp64 redo, {O.simd_isa()} vectors over haplotypes, OpenMP over reads, on {cpu_model()}",
             "scalar_fp64_oracle": {"value": round(s2.cells / dt2 / 1e9, 3), "unit": "GCUPS", "cores": threads,
-                                   "sample": f"first {n2} reads ({s2.cells:.3e} cells, {reps2} x {dt2:.2f} s), OpenMP over reads"}}
+                                   "sample": f"first {n2} reads ({s2.cells:.3e} cells, {reps2} x {dt2:.2f} s), OpenMP over reads"},
+            "scalar_fp64_oracle_one_thread": {"value": round(s3.cells / dt3 / 1e9, 3), "unit": "GCUPS", "cores": 1,
+                                              "sample": f"first {n3} reads ({s3.cells:.3e} cells, {reps3} x {dt3:.2f} s)"}}
 
 
 class HostCall:
