@@ -356,10 +356,11 @@ struct RegionPlan {
 // kernels of a region-sized pass have been enqueued, so that the record does not delay them.
 int record_stage_in_event(gatk_pairhmm* h) {
     if (!h->stage_in_record_due) return GATK_PAIRHMM_OK;
-    if (!h->stage_in_copied) HIP_TRY(hipEventCreateWithFlags(&h->stage_in_copied, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(h->stage_in_copied, h->stage_in_unrecorded));
+    hipEvent_t& copied = h->stage_in_copied[h->stage_in_slot];
+    if (!copied) HIP_TRY(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(copied, h->stage_in_unrecorded));
     h->stage_in_record_due = false;
-    h->stage_in_busy = true;
+    h->stage_in_busy[h->stage_in_slot] = true;
     return GATK_PAIRHMM_OK;
 }
 
@@ -434,16 +435,18 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     const size_t bulk_bytes = L.size;
     HIP_TRY(hipSetDevice(h->device));
     if (int rc = record_stage_in_event(h)) return rc;
-    if (h->stage_in_busy) {  // the previous upload's copy out of the staging buffer
-        HIP_TRY(hipEventSynchronize(h->stage_in_copied));
-        h->stage_in_busy = false;
+    h->stage_in_slot ^= 1;  // the other staging buffer: what may still be read out of it is the upload before the last
+    if (h->stage_in_busy[h->stage_in_slot]) {
+        HIP_TRY(hipEventSynchronize(h->stage_in_copied[h->stage_in_slot]));
+        h->stage_in_busy[h->stage_in_slot] = false;
     }
+    pairhmm_host::PinnedBuf& stage_in = h->stage_in_buffers[h->stage_in_slot];
     // room for the rest as well, generously: the buffer is not to move while the copies run
-    HIP_TRY(h->stage_in.ensure(bulk_bytes + static_cast<size_t>(hap_pool_bytes) + static_cast<size_t>(total_reads) * 64 +
+    HIP_TRY(stage_in.ensure(bulk_bytes + static_cast<size_t>(hap_pool_bytes) + static_cast<size_t>(total_reads) * 64 +
                                static_cast<size_t>(total_haps) * 400 + static_cast<size_t>(num_regions) * 512 + (size_t{64} << 10)));
     CopyCrew crew;
     {
-        uint8_t* const S0 = static_cast<uint8_t*>(h->stage_in.p);
+        uint8_t* const S0 = static_cast<uint8_t*>(stage_in.p);
         crew.jobs.reserve(static_cast<size_t>(num_regions) * 5);
         size_t rcur = 0;
         for (int k = 0; k < num_regions; ++k) {
@@ -750,11 +753,11 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     const size_t o_sdescs = L.add((stream_descs.size() + 1) * sizeof(StreamDesc));
     const size_t o_rinfo = L.add((total_reads + 1) * sizeof(ReadInfo));
     const size_t upload_bytes = L.size;
-    if (upload_bytes > h->stage_in.cap) {  // the estimate fell short: let the copies finish, then move what they wrote
+    if (upload_bytes > stage_in.cap) {  // the estimate fell short: let the copies finish, then move what they wrote
         crew.finish();
-        HIP_TRY(h->stage_in.ensure_keep(upload_bytes, bulk_bytes));
+        HIP_TRY(stage_in.ensure_keep(upload_bytes, bulk_bytes));
     }
-    uint8_t* S = static_cast<uint8_t*>(h->stage_in.p);
+    uint8_t* S = static_cast<uint8_t*>(stage_in.p);
     int32_t* roff = reinterpret_cast<int32_t*>(S + o_roff);
     int32_t* rout = reinterpret_cast<int32_t*>(S + o_rout);
     int32_t* hoff = reinterpret_cast<int32_t*>(S + o_hoff);
@@ -1816,8 +1819,10 @@ int gatk_pairhmm_close(gatk_pairhmm* h) try {
     h->scratch.release();
     h->scratch2.release();
     h->scratch3.release();
-    if (h->stage_in_copied) { (void)hipEventSynchronize(h->stage_in_copied); (void)hipEventDestroy(h->stage_in_copied); }
-    h->stage_in.release();
+    for (int k = 0; k < 2; ++k) {
+        if (h->stage_in_copied[k]) { (void)hipEventSynchronize(h->stage_in_copied[k]); (void)hipEventDestroy(h->stage_in_copied[k]); }
+        h->stage_in_buffers[k].release();
+    }
     h->stage_out.release();
     h->done_flag.release();
     h->signal_out.release();

@@ -308,9 +308,13 @@ struct gatk_pairhmm {
     int64_t pipeline_pairs = 98304;  // pairs per part of such a call; 0: never split a call
     int64_t pipeline_cells_per_pair = 80000;  // pairs of more than 100 000 cells count as cells / this towards a part of a cut call; 0: count pairs only
     int64_t pipeline_min_pairs = 6144;  // the halves of a call with less than two parts' worth of pairs are at least this large
-    pairhmm_host::PinnedBuf stage_in, stage_out;  // pinned staging shared by every upload / download on this handle
-    hipEvent_t stage_in_copied = nullptr;  // recorded behind the host-to-device copy out of stage_in
-    bool stage_in_busy = false;
+    // Pinned staging shared by every upload / download on this handle.  Uploads alternate between two staging buffers:
+    // the image of one part of a cut call is put together while the copy of the part before it is still reading the
+    // other buffer (with one buffer the planner waited for that copy before it could write the first byte).
+    pairhmm_host::PinnedBuf stage_in_buffers[2], stage_out;
+    int stage_in_slot = 0;                 // the buffer of the latest upload
+    hipEvent_t stage_in_copied[2] = {nullptr, nullptr};  // recorded behind the host-to-device copy out of each buffer
+    bool stage_in_busy[2] = {false, false};
     hipStream_t stage_in_unrecorded = nullptr;  // stream of an upload whose event is still to be recorded
     bool stage_in_record_due = false;
     bool in_cut_call = false;  // a call cut into overlapped parts is under way: the next part waits for an upload's copy, not for its kernels
