@@ -374,6 +374,39 @@ int64_t pipeline_weight(const gatk_pairhmm_batch& b, int64_t ref_cells) {
     return cells > pairs * kLongPairCells ? std::max(pairs, cells / ref_cells) : pairs;
 }
 
+// Where a call is cut into parts that are planned, copied and scored one behind the other: the regions of part p are
+// [cuts[p], cuts[p + 1]).  weights: what each region counts towards a part (pipeline_weight).
+//   * A large call: parts of about pipeline_pairs, the first ramp_steps of them an eighth, a quarter, a half ... of
+//     that, so that the device starts early (nothing overlaps the planning of the first part).
+//   * A call of less than three parts' worth that has the device to itself and at least 8 mid_ramp_min pairs: four
+//     parts, an eighth, a quarter and twice five sixteenths of it.  (Against two halves, on 64 / 128 / 192 / 256 / 320
+//     HaplotypeCaller-sized regions per call: 3 / 9 / 7 / 16 / 13 % less time.)
+//   * A smaller one that has the device to itself: two halves of at least min_pairs, so that the planning of the
+//     second and the copy back of the first hide behind kernels; below two min_pairs, one part.
+// No cut leaves less than half a part behind it.
+struct CutRules { int64_t pipeline_pairs, min_pairs, mid_ramp_min; bool ramp; int ramp_steps; bool device_is_shared; };
+std::vector<int> part_cuts(const std::vector<int64_t>& weights, const CutRules& rules) {
+    const int n = static_cast<int>(weights.size());
+    std::vector<int> cuts{0};
+    if (rules.pipeline_pairs > 0) {
+        int64_t acc = 0, total = 0, taken = 0;
+        for (const int64_t w : weights) total += w;
+        const int64_t part_pairs = rules.device_is_shared ? rules.pipeline_pairs
+                                 : std::max(std::min(rules.min_pairs, rules.pipeline_pairs), std::min(rules.pipeline_pairs, total / 2));
+        const bool ramp = rules.ramp && total >= 3 * part_pairs;
+        const bool mid_ramp = rules.ramp && !ramp && !rules.device_is_shared && total >= 8 * rules.mid_ramp_min;
+        for (int k = 0; k < n; ++k) {
+            acc += weights[static_cast<size_t>(k)]; taken += weights[static_cast<size_t>(k)];
+            const int part = static_cast<int>(cuts.size()) - 1;
+            const int64_t want = mid_ramp ? (part == 0 ? total / 8 : part == 1 ? total / 4 : 5 * total / 16)
+                                          : !ramp || part >= rules.ramp_steps ? part_pairs : part_pairs >> (rules.ramp_steps - part);
+            if (acc >= want && k + 1 < n && 2 * (total - taken) >= (mid_ramp ? want : part_pairs)) { cuts.push_back(k + 1); acc = 0; }
+        }
+    }
+    cuts.push_back(n);
+    return cuts;
+}
+
 // checked: the caller has run check_region on these regions already (under their own indices)
 #ifdef PAIRHMM_CALL_CLOCKS
 #define PLAN_CLOCK(i) plan_clock[i] = now_ms()
@@ -1338,33 +1371,10 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
             num_regions = static_cast<int>(pieces.size());
         }
     }
-    // parts of about pipeline_pairs (weighted) pairs, cut between regions; the first three are an eighth, a quarter and a half of
-    // that, so that the device starts early (nothing overlaps the planning of the first part)
-    std::vector<int> cuts{0};
-    if (h->pipeline_pairs > 0) {
-        int64_t acc = 0, total = 0, taken = 0;
-        for (int k = 0; k < num_regions; ++k) total += weight_of(regions[k]);
-        // a call of less than two parts' worth is cut in two halves, down to pipeline_min_pairs each, so that
-        // the planning of the second half and the copy back of the first hide behind kernels
-        const int64_t part_pairs = in_flight.others > 0 ? h->pipeline_pairs
-                                 : std::max(std::min(h->pipeline_min_pairs, h->pipeline_pairs), std::min(h->pipeline_pairs, total / 2));
-        const bool ramp = h->pipeline_ramp && total >= 3 * part_pairs;
-        // A call of less than three parts' worth that has the device to itself is cut in four, an eighth, a quarter and
-        // twice five sixteenths of it: the device starts after the planning of an eighth, and each part's planning and
-        // copy back hide behind the kernels of its neighbours.  (Against two halves, on 64 / 128 / 192 / 256 / 320
-        // HaplotypeCaller-sized regions per call: 3 / 9 / 7 / 16 / 13 % less time.)
-        const bool mid_ramp = h->pipeline_ramp && !ramp && in_flight.others == 0 && total >= 8 * h->pipeline_mid_ramp_min;
-        for (int k = 0; k < num_regions; ++k) {
-            const int64_t w = weight_of(regions[k]);
-            acc += w; taken += w;
-            const size_t part = cuts.size() - 1;
-            const int64_t want = mid_ramp ? (part == 0 ? total / 8 : part == 1 ? total / 4 : 5 * total / 16)
-                                          : !ramp || static_cast<int>(part) >= h->pipeline_ramp_steps ? part_pairs : part_pairs >> (h->pipeline_ramp_steps - static_cast<int>(part));
-            // no cut that leaves less than half a part behind it
-            if (acc >= want && k + 1 < num_regions && 2 * (total - taken) >= (mid_ramp ? want : part_pairs)) { cuts.push_back(k + 1); acc = 0; }
-        }
-    }
-    cuts.push_back(num_regions);
+    std::vector<int64_t> weights(static_cast<size_t>(num_regions));
+    for (int k = 0; k < num_regions; ++k) weights[static_cast<size_t>(k)] = weight_of(regions[k]);
+    std::vector<int> cuts = part_cuts(weights, CutRules{h->pipeline_pairs, h->pipeline_min_pairs, h->pipeline_mid_ramp_min, h->pipeline_ramp,
+                                                        h->pipeline_ramp_steps, in_flight.others > 0});
     const bool are_pieces = !pieces.empty();
     for (gatk_pairhmm_resident* R : {&h->scratch, &h->scratch2, &h->scratch3}) { R->region_label_base = 0; R->regions_are_pieces = false; }
     // an input error found in a read-range piece is reported under the caller's own region and read index
@@ -2074,6 +2084,26 @@ extern "C" int gatk_pairhmm_debug_fail_share(int index) {
     g_fail_share_for_test = index;
     return GATK_PAIRHMM_OK;
 }
+
+// Test hook (not in the header, touches no device): where a call whose regions weigh `weights` would be cut into parts
+// under the default rules of a handle (shared != 0: other calls are under way on the device).  Writes the cut
+// positions, the first 0 and the last num_regions, and returns how many there are (or -1 when `capacity` is too small).
+extern "C" int gatk_pairhmm_debug_part_cuts(const int64_t* weights, int32_t num_regions, int32_t shared, int32_t* cuts, int32_t capacity) try {
+    const gatk_pairhmm defaults;
+    const std::vector<int> c = part_cuts(std::vector<int64_t>(weights, weights + std::max(num_regions, 0)),
+                                         CutRules{defaults.pipeline_pairs, defaults.pipeline_min_pairs, defaults.pipeline_mid_ramp_min,
+                                                  defaults.pipeline_ramp, defaults.pipeline_ramp_steps, shared != 0});
+    if (static_cast<int>(c.size()) > capacity) return -1;
+    for (size_t k = 0; k < c.size(); ++k) cuts[k] = c[k];
+    return static_cast<int>(c.size());
+} catch (...) { return -1; }
+
+// Test hook (not in the header, touches no device): rows per lane of a wave-group whose longest read has `longest`
+// bases in a large call, when only the values whose bits are set in `allowed` may be chosen (0: every value).
+extern "C" int gatk_pairhmm_debug_group_rows(int32_t longest, uint32_t allowed) try {
+    if (longest < 1 || longest > kWave * kMaxRowsPerLane - 2) return -1;
+    return allowed ? group_rows_table(allowed)[static_cast<size_t>(longest)] : choose_group_rows_per_lane(longest);
+} catch (...) { return -1; }
 
 // An engine of a device's dispatcher: a single-device handle that is nobody's own.
 int pairhmm_host::create_shared_engine(int device, bool squash, gatk_pairhmm** out) {

@@ -108,3 +108,63 @@ def test_register_spills_of_the_shipped_kernels_go_to_scratch_memory():
         # only the instantiations known to need more than the register file: fp64, 9 rows per lane and more
         m = re.search(r"fwd_(?:direct|list)IdLi(\d+)|fwd_pairsILi(\d+)", name)
         assert m and int(m.group(1) or m.group(2)) >= 9, f"unexpected register spills in {name}"
+
+
+def _part_cuts(weights, shared=False):
+    import ctypes as C
+    lib = pairhmm.load_library()
+    lib.gatk_pairhmm_debug_part_cuts.restype = C.c_int
+    w = (C.c_int64 * len(weights))(*weights)
+    out = (C.c_int32 * (len(weights) + 2))()
+    n = lib.gatk_pairhmm_debug_part_cuts(w, len(weights), 1 if shared else 0, out, len(out))
+    assert n >= 2
+    cuts = list(out[:n])
+    assert cuts[0] == 0 and cuts[-1] == len(weights) and cuts[1:] == sorted(set(cuts[1:]))
+    return cuts
+
+
+def test_where_a_call_is_cut_into_overlapped_parts():
+    """Host logic of the overlapped call (no device involved): a small call stays whole, from 12 288 pairs on it is cut
+    in two halves, from 30 720 in four growing parts, and a large one into parts of 98 304 pairs behind a ramp of an
+    eighth, a quarter and a half; a call that shares the device is cut at full parts only; the last part is never
+    a sliver."""
+    region = 600  # pairs per region
+    parts = lambda cuts: [region * (b - a) for a, b in zip(cuts, cuts[1:])]
+    assert _part_cuts([region] * 15) == [0, 15]                       # 9 000 pairs: one part
+    halves = parts(_part_cuts([region] * 30))                         # 18 000 pairs
+    assert len(halves) == 2 and min(halves) >= 6144
+    four = parts(_part_cuts([region] * 100))                          # 60 000 pairs
+    assert len(four) == 4 and four[:3] == sorted(four[:3]) and four[0] <= 60000 // 8 + region and min(four) >= 60000 // 8 and sum(four) == 60000
+    mid = parts(_part_cuts([region] * 400))                           # 240 000 pairs: still four parts, none above a full part
+    assert len(mid) == 4 and max(mid) <= 98304
+    large = parts(_part_cuts([region] * 2000))                        # 1.2 M pairs
+    assert large[0] <= 98304 // 8 + region and large[1] <= 98304 // 4 + region and large[2] <= 98304 // 2 + region
+    assert all(98304 <= p < 98304 + region for p in large[3:-1]) and large[-1] >= 98304 // 2 and sum(large) == 1200000
+    shared = parts(_part_cuts([region] * 400, shared=True))
+    assert all(98304 <= p < 98304 + region for p in shared[:-1]) and len(shared) == 2
+    assert _part_cuts([region] * 100, shared=True) == [0, 100]
+    # one region heavier than a part is a part of its own; empty regions change nothing
+    lumpy = _part_cuts([0, 500000, 0, 10, 0, 200000, 3, 0])
+    assert lumpy[1] == 2 and lumpy[-1] == 8
+    assert _part_cuts([]) == [0, 0]  # no regions: one empty part
+
+
+def test_rows_per_lane_of_a_wave_group():
+    """Host logic (no device involved): whatever rows-per-lane value the planner gives a wave-group, the group's longest
+    read with its pad and sum rows fits the 64 lanes; the value is one the kernels are built for; a restricted set is
+    honoured wherever one of its values fits, and ignored (not violated into a misfit) where none does."""
+    lib = pairhmm.load_library()
+    built = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16}
+    for longest in range(1, 1023):
+        k = lib.gatk_pairhmm_debug_group_rows(longest, 0)
+        assert k in built and 64 * k >= longest + 2, (longest, k)
+        assert k <= 12 or longest + 2 > 64 * 12  # 14 and 16 rows cost a wave per SIMD: only for reads that need them
+    allowed = (1 << 9) | (1 << 10)
+    for longest in range(1, 1023):
+        k = lib.gatk_pairhmm_debug_group_rows(longest, allowed)
+        assert k in built and 64 * k >= longest + 2
+        if longest + 2 <= 64 * 10:
+            assert k in (9, 10), (longest, k)
+    assert lib.gatk_pairhmm_debug_group_rows(0, 0) == -1 and lib.gatk_pairhmm_debug_group_rows(1023, 0) == -1
+    # the HaplotypeCaller read lengths: five values in use, each a tight fit
+    assert {lib.gatk_pairhmm_debug_group_rows(n, 0) for n in range(121, 152)} == {7, 8, 9, 10, 11}
