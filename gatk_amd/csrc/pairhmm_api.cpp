@@ -241,9 +241,9 @@ int check_region(const gatk_pairhmm_batch& b, int k, int* read_max_out, int* hap
     if (hap_max <= 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "HAPLOTYPE_MAX_LENGTH must be > 0 but got " + std::to_string(hap_max) + where());
     if (b.num_haps > 0 && hap_min == 0)
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("zero-length haplotype: the reference result is undefined") + where());
-    if (read_max > kWave * kMaxRowsPerLane - 2)
+    if (read_max > kMaxReadLen)
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "readBases is too long, got " + std::to_string(read_max) + " but max is " +
-                                                       std::to_string(kWave * kMaxRowsPerLane - 2) + where());
+                                                       std::to_string(kMaxReadLen) + where());
     if (hap_max > kMaxHapLen)
         return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "Haplotype bases is too long, got " + std::to_string(hap_max) + " but max is " +
                                                        std::to_string(kMaxHapLen) + where());
@@ -514,15 +514,18 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             const gatk_pairhmm_batch& b = regions[k];
             if (b.num_reads == 0 || b.num_haps == 0) continue;
             int nonempty = 0, region_longest = 0;
+            int64_t grouped_bytes = 0;
             for (int r = 0; r < b.num_reads; ++r) {
                 const int len = b.read_offsets[r + 1] - b.read_offsets[r];
+                if (len <= 0 || len > kMaxGroupedReadLen) continue;  // no rows, or the long-read pass: no wave-group either way
                 region_longest = std::max(region_longest, len);
-                nonempty += len > 0;
+                grouped_bytes += len;
+                ++nonempty;
             }
             if (nonempty == 0) continue;
             longest = std::max(longest, region_longest);
             // reads are packed longest first: between the mean and the longest is what decides how many share a wave
-            const double mean_len = static_cast<double>(b.read_offsets[b.num_reads] - b.read_offsets[0]) / nonempty;
+            const double mean_len = static_cast<double>(grouped_bytes) / nonempty;
             shapes.push_back(RegionShape{nonempty, b.num_haps, 0.5 * (mean_len + region_longest),
                                          static_cast<double>(b.hap_offsets[b.num_haps] - b.hap_offsets[0]) / b.num_haps});
         }
@@ -536,6 +539,8 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     std::vector<SegDesc> segs;
     segs.reserve(static_cast<size_t>(total_reads));
     std::vector<int32_t> neg_inf_idx;
+    std::vector<RerunPair> long_pairs;  // the pairs of reads too long for a wave-group
+    int long_hap_max = 0;
     std::vector<int> order, lens_desc, len_slot;
     std::vector<ReadInfo> read_info(static_cast<size_t>(total_reads));
     std::vector<StreamDesc> stream_descs;
@@ -562,7 +567,10 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             const int len = b.read_offsets[r + 1] - b.read_offsets[r];
             len_total += len;
             read_info[rp.read_begin + r] = ReadInfo{rp.hap_begin, nh, -1, k};
-            if (len > 0) {
+            if (len > kMaxGroupedReadLen) {  // more rows than a wave holds: every pair of the read goes to the long-read pass
+                for (int a = 0; a < nh; ++a) long_pairs.push_back(RerunPair{rp.read_begin + r, a});
+                long_hap_max = std::max(long_hap_max, rp.hap_max);
+            } else if (len > 0) {
                 read_max = std::max(read_max, len);
                 read_min = std::min(read_min, len);
                 ++nonempty;
@@ -581,12 +589,12 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             len_slot.assign(static_cast<size_t>(read_max - read_min + 2), 0);
             for (int r = 0; r < nr; ++r) {
                 const int len = b.read_offsets[r + 1] - b.read_offsets[r];
-                if (len > 0) ++len_slot[read_max - len + 1];  // slot 0: the longest
+                if (len > 0 && len <= kMaxGroupedReadLen) ++len_slot[read_max - len + 1];  // slot 0: the longest
             }
             for (size_t i = 1; i < len_slot.size(); ++i) len_slot[i] += len_slot[i - 1];
             for (int r = 0; r < nr; ++r) {
                 const int len = b.read_offsets[r + 1] - b.read_offsets[r];
-                if (len <= 0) continue;
+                if (len <= 0 || len > kMaxGroupedReadLen) continue;
                 const int at = len_slot[read_max - len]++;
                 order[at] = r;
                 lens_desc[at] = len;
@@ -785,6 +793,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     const size_t o_hsoff = L.add((total_haps + 1) * sizeof(int32_t));
     const size_t o_sdescs = L.add((stream_descs.size() + 1) * sizeof(StreamDesc));
     const size_t o_rinfo = L.add((total_reads + 1) * sizeof(ReadInfo));
+    const size_t o_long = L.add((long_pairs.size() + 1) * sizeof(RerunPair));
     const size_t upload_bytes = L.size;
     if (upload_bytes > stage_in.cap) {  // the estimate fell short: let the copies finish, then move what they wrote
         crew.finish();
@@ -838,6 +847,9 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     if (!neg_inf_idx.empty()) memcpy(S + o_neg, neg_inf_idx.data(), neg_inf_idx.size() * sizeof(int32_t));
     if (!stream_descs.empty()) memcpy(S + o_sdescs, stream_descs.data(), stream_descs.size() * sizeof(StreamDesc));
     if (!read_info.empty()) memcpy(S + o_rinfo, read_info.data(), read_info.size() * sizeof(ReadInfo));
+    if (!long_pairs.empty()) memcpy(S + o_long, long_pairs.data(), long_pairs.size() * sizeof(RerunPair));
+    R->num_long_pairs = static_cast<int32_t>(long_pairs.size());
+    R->long_hap_max = long_hap_max;
     R->hap_stream_entries = scur + kStreamBackPad;
     if (R->hap_stream_entries >= (size_t{1} << 31)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "more than 2^31 haplotype bases in one call");
     const double t_planned = now_ms();
@@ -878,6 +890,8 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     B.hap_stream_off = reinterpret_cast<const int32_t*>(D + o_hsoff);
     B.stream_descs = reinterpret_cast<const StreamDesc*>(D + o_sdescs);
     B.read_info = reinterpret_cast<const ReadInfo*>(D + o_rinfo);
+    B.long_pairs = reinterpret_cast<const RerunPair*>(D + o_long);
+    B.num_long_pairs = R->num_long_pairs;
     B.hap_stream = R->d_hap_stream.as<uint16_t>();
     B.raw_out = R->d_raw_out.as<float>();
     B.pair_lists = R->d_pair_lists.as<RerunPair>();
@@ -938,8 +952,9 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     B.pair_counts = R->counters() + 1 + kMaxBuckets;
     const bool streaming = R->any_stream && !h->force_fp64;
     // A region-sized call on the one-haplotype pass skips the expansion launch: the forward kernel works the
-    // row constants out itself (and makes the quality checks), one launch less in a chain of five.
-    const bool rows_in_kernel = !streaming && !h->force_fp64 && R->total_pairs < 2 * static_cast<int64_t>(h->wave_slots);
+    // row constants out itself (and makes the quality checks), one launch less in a chain of five.  Not with reads
+    // of the long-read pass in the call: their qualities are checked by the expansion launch only.
+    const bool rows_in_kernel = !streaming && !h->force_fp64 && R->num_long_pairs == 0 && R->total_pairs < 2 * static_cast<int64_t>(h->wave_slots);
     if (rows_in_kernel) {
         B.row_consts = nullptr;
         if (R->num_neg_inf > 0) {  // only the -infinity fill of zero-length reads is left of the prepare pass
@@ -949,6 +964,16 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
         }
     } else {
         HIP_TRY(launch_prepare(B, !h->force_fp64, streaming, s));
+    }
+    if (R->num_long_pairs > 0) {
+        // a wave per pair, at most kLongWaves of them at once; each owns two boundary rows of {diagonal term, insertion mass}
+        const int waves = std::min<int>(R->num_long_pairs, kLongWaves);
+        const int stride = (R->long_hap_max + 63) & ~63;
+        HIP_TRY(R->d_long_boundary.ensure(static_cast<size_t>(waves) * 4 * static_cast<size_t>(stride) * sizeof(double)));
+        DeviceBatch Lg = B;
+        Lg.long_boundary = R->d_long_boundary.as<double>();
+        Lg.long_boundary_stride = stride;
+        HIP_TRY(launch_long(Lg, waves, s));
     }
     if (timing) HIP_TRY(hipEventRecord(ev[1], s));
     auto bucket_args = [&](size_t bi, int mode) {

@@ -26,6 +26,8 @@ enum EmitMode : int {
     kEmitLut5 = 3,      // haplotypes are A/C/G/T/N only: table with an 'N' column
 };
 
+constexpr int kMaxGroupedReadLen = kWave * kMaxRowsPerLane - 2;  // longest read a wave-group holds (a pad row in front, the sum row behind)
+constexpr int kMaxReadLen = 32766;  // longer reads are refused; reads beyond kMaxGroupedReadLen go through the long-read pass
 constexpr int kMaxHapLen = 16000;  // one wave's LDS image must fit in a quarter of a 64 KiB block allocation
 
 // A wave-group packs one or more reads into the 64 lanes of a wavefront: a read of length R takes
@@ -152,6 +154,11 @@ struct DeviceBatch {
     const int32_t* pair_count;     // = pair_counts + bucket
     const RerunPair* pair_list;    // = pair_lists + bucket_pair_begin[bucket]
     int32_t slot_lanes;            // lanes every pair gets: enough for the bucket's longest read
+    // long-read pass: the pairs of reads too long for one wave's 64 x 16 rows
+    const RerunPair* long_pairs;   // [num_long_pairs]
+    int32_t num_long_pairs;
+    int32_t long_boundary_stride;  // entries of one boundary row (the launch's longest haplotype, rounded up)
+    double* long_boundary;         // [waves of the launch][2 rows][long_boundary_stride][2]: what a chunk of rows hands the chunk below it, per column
     int32_t num_region_descs;
     int32_t num_tasks;             // this launch's work items
     const double* err_prob;        // [256]

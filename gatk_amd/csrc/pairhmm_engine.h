@@ -39,6 +39,7 @@ int stream_lds_bytes_per_wave(int rows_per_lane, int emit_mode);
 hipError_t launch_stream(const DeviceBatch& B, int rows_per_lane, int emit_mode, hipStream_t stream);
 hipError_t launch_finish_stream(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int waves, hipStream_t stream);
+hipError_t launch_long(const DeviceBatch& B, int waves, hipStream_t stream);
 hipError_t launch_normalize_reads(const DeviceBatch& B, const int32_t* reference_allele_index, int best_to_zero, double cap, hipStream_t stream);
 hipError_t launch_flag_poorly_modelled_reads(const DeviceBatch& B, double maximum_error_per_base, uint8_t* flags, hipStream_t stream);
 hipError_t launch_marginalize_reads(const DeviceBatch& B, const int32_t* old_to_new, const int64_t* new_base, const int32_t* new_count,
@@ -125,6 +126,7 @@ struct PinnedBuf {
     }
 };
 
+constexpr int kLongWaves = 512;  // waves of a long-read launch (one pair each at a time)
 constexpr size_t kCounterBytes = 256;  // device counters of a pass: error word, rerun-list lengths, pair-list lengths, first bad read
 constexpr int kErrorReadSlot = 1 + 2 * kMaxBuckets;  // counters[kErrorReadSlot]: INT32_MAX - index of the first read with an input error, 0 = none
 static_assert((kErrorReadSlot + 1) * sizeof(int32_t) <= kCounterBytes, "counter block");
@@ -229,6 +231,9 @@ struct gatk_pairhmm_resident {
     double* out() const { return reinterpret_cast<double*>(d_out.as<uint8_t>() + pairhmm_host::kCounterBytes); }
     pairhmm_host::DevBuf d_row_consts;  // fp32 row constants of every read, written on the device
     pairhmm_host::DevBuf d_hap_stream, d_raw_out, d_pair_lists;  // fp32 stream pass and the fp64 pair pass behind it
+    pairhmm_host::DevBuf d_long_boundary;  // long-read pass: two boundary rows per wave
+    int32_t num_long_pairs = 0;            // pairs of reads too long for a wave-group
+    int long_hap_max = 0;                  // longest haplotype among them
     size_t hap_stream_entries = 0;
     std::vector<int32_t> region_reads, region_haps;     // per region of the call (0 haplotypes when it has no reads)
     std::vector<int32_t> region_read_begin, region_hap_begin;  // global index of a region's first read / haplotype
@@ -245,7 +250,7 @@ struct gatk_pairhmm_resident {
     std::vector<EventSet> ev_pending, ev_free;
     gatk_pairhmm_stats last_timing{};
     void release() {
-        for (pairhmm_host::DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_row_consts, &d_hap_stream, &d_raw_out, &d_pair_lists, &d_epilogue}) b->release();
+        for (pairhmm_host::DevBuf* b : {&d_arena, &d_out, &d_rerun_lists, &d_row_consts, &d_hap_stream, &d_raw_out, &d_pair_lists, &d_long_boundary, &d_epilogue}) b->release();
         counters_clear = false;
         if (ev_downloaded) (void)hipEventDestroy(ev_downloaded);
         ev_downloaded = nullptr;

@@ -1407,6 +1407,138 @@ __global__ void __launch_bounds__(kWave) fwd_pairs(const DeviceBatch B) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Long-read pass
+// ---------------------------------------------------------------------------------------------
+// A read of more than 64 x 16 - 2 bases does not fit the rows of one wave.  Its pairs are scored by one wave each, in
+// double and in the plain arithmetic form (as the fp64 pair pass: the reference's operations in linear space with the
+// 2^1020 initial condition), chunk of rows by chunk of rows: a chunk is 64 lanes x kLongRows rows, swept over the whole
+// haplotype like any wave-group; what the chunk's last lane hands downwards in every column (the diagonal term and the
+// insertion mass, the two values a lane takes from the lane above it) goes to a boundary row in global memory, and the
+// first lane of the chunk below reads it there in the same column.  Rows are laid out as everywhere else: pad rows in
+// front, the read's rows, the sum row last.  Emission terms come from comparing the bytes (no table: the rows change
+// with every chunk).  A correctness path, not a fast one: such reads are no HaplotypeCaller input.
+constexpr int kLongRows = 8;
+
+__device__ __forceinline__ void run_long_pair(const DeviceBatch& B, const RerunPair pr, double* boundary, const int lane) {
+    using T = double;
+    constexpr int K = kLongRows;
+    const int ro = B.read_off[pr.read_idx];
+    const int R = B.read_off[pr.read_idx + 1] - ro;
+    const int hap = B.read_info[pr.read_idx].hap_begin + pr.hap_local;
+    const int H = B.hap_len[hap];
+    const uint8_t* const hb = B.hap_pool + B.hap_off[hap];
+    const int total_lanes = (R + 1 + K) / K;  // rows >= R + 2
+    const int chunks = (total_lanes + kWave - 1) / kWave;
+    const T initD = static_cast<T>(::ldexp(1.0, Scale<T>::kExp2) / static_cast<double>(H));
+    const int stride = B.long_boundary_stride;
+    T total = 0.0;
+    for (int chunk = 0; chunk < chunks; ++chunk) {
+        const int g = chunk * kWave + lane;  // this lane's place among all lanes of the pair
+        const bool used = g < total_lanes;
+        const int first_row = g * K + 1 - (total_lanes * K - R - 1);  // pads | rows 1..R | sum row
+        const bool seg_last = g == total_lanes - 1;
+        // what the chunk above left per column, and where this chunk leaves its own: {diagonal term, insertion mass}
+        // (read and written through the device-coherent cache level: the reader is another lane of the same wave, a chunk later)
+        double* const above = boundary + static_cast<size_t>((chunk + 1) & 1) * 2 * stride;
+        double* const below = boundary + static_cast<size_t>(chunk & 1) * 2 * stride;
+        Rows<T, K> w;
+        T P[K], Q[K];
+        unsigned xb[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int i = first_row + r;
+            double p = 0, q = 0, t4 = 0, t5 = 0, t0n = 0, t1n = 0, t2n = 0, t3n = 0;
+            bool pad = false, has_next = false;
+            xb[r] = kNoBase;
+            const bool sum_row = used && i == R + 1;
+            const bool last_row = used && i == R;
+            if (sum_row) {
+                p = q = 1.0;
+                t5 = 1.0;
+            } else if (used) {
+                if (i >= 1) {
+                    const unsigned x = B.read_bases[ro + i - 1];
+                    const double e = B.err_prob[effective_qual(B, ro + i - 1, pr.read_idx)];
+                    xb[r] = x;
+                    p = 1.0 - e;
+                    q = (x == 'N') ? p : e / B.mismatch_divisor;
+                    t4 = B.err_prob[del_byte_at(B, ro + i - 1) & 127u];
+                    t5 = B.err_prob[gcp_byte_at(B, ro + i - 1)];
+                } else {
+                    pad = true;
+                    t4 = 1.0;
+                    t5 = 1.0;
+                    if (i < 0) t1n = 1.0;
+                }
+                if (i >= 0 && i < R) {
+                    const unsigned ins = ins_byte_at(B, ro + i) & 127u, del = del_byte_at(B, ro + i) & 127u;
+                    const double eg = B.err_prob[gcp_byte_at(B, ro + i)];
+                    has_next = true;
+                    t0n = B.match_to_match[ins * 128u + del];
+                    t1n = 1.0 - eg;
+                    t2n = B.err_prob[ins];
+                    t3n = eg;
+                }
+            }
+            const bool real_next = has_next && i >= 1;
+            P[r] = p;
+            Q[r] = q;
+            w.T5[r] = t5;
+            w.A[r] = real_next ? t0n : last_row ? 1.0 : 0.0;
+            w.B[r] = last_row ? 1.0 : t1n;
+            w.C[r] = real_next ? t2n : 0.0;
+            w.D[r] = real_next ? t3n : 0.0;
+            w.E[r] = t4 * t1n;
+            w.Ml[r] = 0.0;
+            w.El[r] = pad ? initD : 0.0;  // column 0
+        }
+#pragma unroll
+        for (int r = 1; r < K; ++r) w.Sd[r] = w.El[r - 1] * w.E[r - 1];
+        w.Sout = w.El[K - 1] * w.E[K - 1];
+        w.Iout = 0.0;
+        w.Sd[0] = shr1(w.Sout);  // the first lane of a chunk below the first: the row above it is a read row, whose column 0 holds nothing
+        const int steps = H + kWave - 1;
+        for (int s = 0; s < steps; ++s) {
+            T Sin = shr1(w.Sout);
+            T Iin = shr1(w.Iout);
+            const int j = s - lane;  // this lane's column (0-based haplotype position)
+            const bool in_hap = used && j >= 0 && j < H;
+            if (chunk > 0 && lane == 0 && in_hap) {
+                Sin = __hip_atomic_load(above + 2 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                Iin = __hip_atomic_load(above + 2 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (in_hap) {
+                const unsigned y = hb[j];
+                T prior[K];
+#pragma unroll
+                for (int r = 0; r < K; ++r) prior[r] = (xb[r] == y || y == 'N') ? P[r] : Q[r];  // a read 'N' has Q = P
+                column<T, K>(w, prior, Sin, Iin);
+                if (lane == kWave - 1 && chunk + 1 < chunks) {
+                    __hip_atomic_store(below + 2 * j, w.Sout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(below + 2 * j + 1, w.Iout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (used && seg_last) total = w.El[K - 1] + w.Ml[K - 1] + w.Sd[K - 1];  // the sum row
+        // the chunk below reads what this one has written: every store of the wave is done before its first load
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int last_lane = (total_lanes - 1) & (kWave - 1);
+    if (lane == last_lane) B.out[B.read_out_base[pr.read_idx] + pr.hap_local] = ::log10(total) - Scale<T>::kExp2 * 0.30102999566398119521;
+}
+
+// One wave per block and pair; a block owns two boundary rows.
+__global__ void __launch_bounds__(kWave) fwd_long(const DeviceBatch B) {
+    const int lane = threadIdx.x;
+    double* const boundary = B.long_boundary + static_cast<size_t>(blockIdx.x) * 4 * B.long_boundary_stride;
+    for (int p = blockIdx.x; p < B.num_long_pairs; p += gridDim.x) {
+        run_long_pair(B, B.long_pairs[p], boundary, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The steps right behind the path (genotyper/ReadLikelihoods.java), on the results still on the device.
 // out is read-major: a read's likelihoods against its region's alleles are consecutive.  One thread per read.
 // ---------------------------------------------------------------------------------------------
@@ -1659,6 +1791,13 @@ hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int waves, hipS
 #undef PAIRHMM_PAIRS_CASE
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// Enqueue the long-read pass (B.long_pairs / num_long_pairs / long_boundary / long_boundary_stride set); waves: one-wave blocks.
+hipError_t launch_long(const DeviceBatch& B, int waves, hipStream_t stream) {
+    if (waves <= 0 || B.num_long_pairs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fwd_long, dim3(waves), dim3(kWave), 0, stream, B);
     return hipGetLastError();
 }
 

@@ -191,6 +191,74 @@ def test_batches_of_long_reads(hmm, oracle, read_len, jitter):
         hmm.set_option("stream_mode", 1)
 
 
+def _near_copy(rng, hap, start, length, every=37):
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    read = hap[start:start + length].copy()
+    read[::every] = acgt[(np.searchsorted(acgt, read[::every]) + 1) % 4]
+    return read
+
+
+@pytest.mark.parametrize("length", [1023, 1030, 1534, 2047, 2500, 4099])
+def test_reads_longer_than_a_wave_holds(hmm, oracle, length):
+    """A read of more than 1022 bases has more rows than the 64 x 16 of one wave: its pairs go through the long-read
+    pass (double, chunk of rows by chunk of rows).  Lengths around the chunk edges (a chunk is 512 rows: 1023 and
+    1030 take three, 1534 exactly three with one pad row, 2047 four, 4099 nine), each against a longer haplotype,
+    a shorter one and one with 'N's, cut from their haplotype so that the likelihoods are finite."""
+    rng = np.random.default_rng(7000 + length)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    hap = acgt[rng.integers(0, 4, length + 170)]
+    with_n = hap[:length + 90].copy()
+    with_n[::101] = ord("N")
+    read = _near_copy(rng, hap, 40, length)
+    quals = rng.integers(10, 40, length)
+    gop = rng.integers(30, 50, length)
+    b = pack([(read, quals, gop, gop[::-1].copy(), rng.integers(8, 12, length))], [hap, hap[:length - 5], with_n])
+    want = ref(oracle, b, 1)
+    assert np.isfinite(want).all()
+    assert_parity(hmm.compute_batch(b), want, tol=1e-9)
+    hmm.set_option("force_fp64", 1)
+    try:
+        assert_parity(hmm.compute_batch(b), want, tol=1e-9)
+    finally:
+        hmm.set_option("force_fp64", 0)
+
+
+def test_long_reads_among_ordinary_ones(hmm, oracle):
+    """Reads for the long-read pass, ordinary reads, a read of exactly 1022 bases (the longest a wave-group takes) and
+    a zero-length read in one region, next to a region of ordinary reads and one that holds a long read only: every
+    row of the result is its read's, whichever pass scored it, in one call and in regions."""
+    rng = np.random.default_rng(71)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    hap = acgt[rng.integers(0, 4, 2100)]
+    other = hap.copy()
+    other[500] = acgt[(np.searchsorted(acgt, other[500]) + 2) % 4]
+    def rec(start, n):
+        return (_near_copy(rng, hap, start, n), rng.integers(10, 40, n), None, None, None)
+    mixed = pack([rec(0, 150), rec(10, 1800), rec(300, 1022), ("", [], [], [], []), rec(100, 1023), rec(700, 90), rec(5, 2000)],
+                 [hap, other, hap[:1900]])
+    ordinary = synth.make_batch(12, 5, 120, 300, seed=72)
+    alone = pack([rec(20, 1300)], [hap[:1500]])
+    wants = [ref(oracle, x, 1) for x in (mixed, ordinary, alone)]
+    assert np.isfinite(wants[0][[0, 1, 2, 4, 5, 6]]).all() and np.isneginf(wants[0][3]).all()
+    assert_parity(hmm.compute_batch(mixed), wants[0])
+    for got, want in zip(hmm.compute_regions([mixed, ordinary, alone]), wants):
+        assert_parity(got, want)
+    for got, want in zip(hmm.compute_regions([alone, mixed]), (wants[2], wants[0])):
+        assert_parity(got, want)
+
+
+def test_a_long_read_with_a_bad_quality_raises_as_any_other(hmm):
+    n = 1500
+    quals = [30] * n
+    quals[1400] = 255
+    with pytest.raises(pairhmm.ArrayIndexOutOfBoundsException):
+        hmm.compute_batch(pack([("ACGT" * (n // 4), quals, None, None, None)], ["ACGT" * 400]))
+    gop = [45] * n
+    gop[1234] = 200
+    with pytest.raises(pairhmm.IllegalArgumentException):
+        hmm.compute_batch(pack([("ACGT" * (n // 4), [30] * n, gop, None, None)], ["ACGT" * 400]))
+
+
 def test_underflow_to_minus_infinity(hmm, oracle):
     b = pack([("A" * 400, [93] * 400, [93] * 400, [93] * 400, [93] * 400), ("ACGT" * 20, [30] * 80, None, None, None)],
              ["C" * 400, "ACGT" * 30])
@@ -277,8 +345,8 @@ def test_error_conventions(hmm):
         hmm.compute_batch(pack([ok], []))
     with pytest.raises(pairhmm.IllegalArgumentException):  # zero-length haplotype: undefined in the reference
         hmm.compute_batch(pack([ok], ["ACGT", ""]))
-    with pytest.raises(pairhmm.IllegalArgumentException):  # read longer than the engine's maximum
-        hmm.compute_batch(pack([("A" * 1023, [30] * 1023, None, None, None)], ["ACGT"]))
+    with pytest.raises(pairhmm.IllegalArgumentException, match="too long"):  # read longer than the engine's maximum
+        hmm.compute_batch(pack([("A" * 32767, [30] * 32767, None, None, None)], ["ACGT"]))
     with pytest.raises(pairhmm.IllegalArgumentException):
         hmm.initialize(0, 10)
     with pytest.raises(pairhmm.IllegalArgumentException):
