@@ -967,13 +967,14 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
     }
     if (R->num_long_pairs > 0) {
         // a wave per pair, at most kLongWaves of them at once; each owns two boundary rows of {diagonal term, insertion mass}
-        const int waves = std::min<int>(R->num_long_pairs, kLongWaves);
         const int stride = (R->long_hap_max + 63) & ~63;
+        const size_t per_wave = 4 * static_cast<size_t>(stride) * sizeof(double);
+        const int waves = static_cast<int>(std::min<size_t>({static_cast<size_t>(R->num_long_pairs), static_cast<size_t>(kLongWaves), std::max<size_t>(kLongBoundaryBytes / per_wave, 256)}));
         HIP_TRY(R->d_long_boundary.ensure(static_cast<size_t>(waves) * 4 * static_cast<size_t>(stride) * sizeof(double)));
         DeviceBatch Lg = B;
         Lg.long_boundary = R->d_long_boundary.as<double>();
         Lg.long_boundary_stride = stride;
-        HIP_TRY(launch_long(Lg, waves, s));
+        HIP_TRY(launch_long(Lg, waves, R->long_hap_max, s));
     }
     if (timing) HIP_TRY(hipEventRecord(ev[1], s));
     auto bucket_args = [&](size_t bi, int mode) {

@@ -39,7 +39,7 @@ int stream_lds_bytes_per_wave(int rows_per_lane, int emit_mode);
 hipError_t launch_stream(const DeviceBatch& B, int rows_per_lane, int emit_mode, hipStream_t stream);
 hipError_t launch_finish_stream(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int waves, hipStream_t stream);
-hipError_t launch_long(const DeviceBatch& B, int waves, hipStream_t stream);
+hipError_t launch_long(const DeviceBatch& B, int waves, int max_hap_len, hipStream_t stream);
 hipError_t launch_normalize_reads(const DeviceBatch& B, const int32_t* reference_allele_index, int best_to_zero, double cap, hipStream_t stream);
 hipError_t launch_flag_poorly_modelled_reads(const DeviceBatch& B, double maximum_error_per_base, uint8_t* flags, hipStream_t stream);
 hipError_t launch_marginalize_reads(const DeviceBatch& B, const int32_t* old_to_new, const int64_t* new_base, const int32_t* new_count,
@@ -126,7 +126,8 @@ struct PinnedBuf {
     }
 };
 
-constexpr int kLongWaves = 512;  // waves of a long-read launch (one pair each at a time)
+constexpr int kLongWaves = 2048;                       // most waves of a long-read launch (one pair each at a time): two per SIMD
+constexpr size_t kLongBoundaryBytes = size_t{256} << 20;  // most memory for their boundary rows (fewer waves when haplotypes are long)
 constexpr size_t kCounterBytes = 256;  // device counters of a pass: error word, rerun-list lengths, pair-list lengths, first bad read
 constexpr int kErrorReadSlot = 1 + 2 * kMaxBuckets;  // counters[kErrorReadSlot]: INT32_MAX - index of the first read with an input error, 0 = none
 static_assert((kErrorReadSlot + 1) * sizeof(int32_t) <= kCounterBytes, "counter block");

@@ -1418,19 +1418,28 @@ __global__ void __launch_bounds__(kWave) fwd_pairs(const DeviceBatch B) {
 // front, the read's rows, the sum row last.  Emission terms come from comparing the bytes (no table: the rows change
 // with every chunk).  A correctness path, not a fast one: such reads are no HaplotypeCaller input.
 constexpr int kLongRows = 8;
+constexpr int kLongStageBytes = kWave * 16;  // one block of boundary columns: {diagonal term, insertion mass} per column
 
-__device__ __forceinline__ void run_long_pair(const DeviceBatch& B, const RerunPair pr, double* boundary, const int lane) {
+// lds: [kLongStageBytes: the boundary columns of the current block of 64 steps][the haplotype's bytes]
+__device__ __forceinline__ void run_long_pair(const DeviceBatch& B, const RerunPair pr, double* boundary, unsigned char* lds, const int lane) {
     using T = double;
     constexpr int K = kLongRows;
     const int ro = B.read_off[pr.read_idx];
     const int R = B.read_off[pr.read_idx + 1] - ro;
     const int hap = B.read_info[pr.read_idx].hap_begin + pr.hap_local;
     const int H = B.hap_len[hap];
-    const uint8_t* const hb = B.hap_pool + B.hap_off[hap];
     const int total_lanes = (R + 1 + K) / K;  // rows >= R + 2
     const int chunks = (total_lanes + kWave - 1) / kWave;
     const T initD = static_cast<T>(::ldexp(1.0, Scale<T>::kExp2) / static_cast<double>(H));
     const int stride = B.long_boundary_stride;
+    double2* const stage = reinterpret_cast<double2*>(lds);
+    uint8_t* const hb = lds + kLongStageBytes;
+    {   // the haplotype into LDS, four bytes a lane (haplotypes start at multiples of 16 in the pool and are padded to one)
+        const uint8_t* const src = B.hap_pool + B.hap_off[hap];
+        for (int j = lane * 4; j < H; j += kWave * 4)
+            *reinterpret_cast<uint32_t*>(hb + j) = *reinterpret_cast<const uint32_t*>(src + j);
+    }
+    __syncthreads();
     T total = 0.0;
     for (int chunk = 0; chunk < chunks; ++chunk) {
         const int g = chunk * kWave + lane;  // this lane's place among all lanes of the pair
@@ -1441,15 +1450,15 @@ __device__ __forceinline__ void run_long_pair(const DeviceBatch& B, const RerunP
         // (read and written through the device-coherent cache level: the reader is another lane of the same wave, a chunk later)
         double* const above = boundary + static_cast<size_t>((chunk + 1) & 1) * 2 * stride;
         double* const below = boundary + static_cast<size_t>(chunk & 1) * 2 * stride;
+        const bool from_above = chunk > 0;
         Rows<T, K> w;
         T P[K], Q[K];
-        unsigned xb[K];
+        unsigned xw[K / 4] = {};  // the rows' read bytes, four to a word (0: a row without a base, which no haplotype byte equals)
 #pragma unroll
         for (int r = 0; r < K; ++r) {
             const int i = first_row + r;
             double p = 0, q = 0, t4 = 0, t5 = 0, t0n = 0, t1n = 0, t2n = 0, t3n = 0;
             bool pad = false, has_next = false;
-            xb[r] = kNoBase;
             const bool sum_row = used && i == R + 1;
             const bool last_row = used && i == R;
             if (sum_row) {
@@ -1459,7 +1468,7 @@ __device__ __forceinline__ void run_long_pair(const DeviceBatch& B, const RerunP
                 if (i >= 1) {
                     const unsigned x = B.read_bases[ro + i - 1];
                     const double e = B.err_prob[effective_qual(B, ro + i - 1, pr.read_idx)];
-                    xb[r] = x;
+                    xw[r >> 2] |= x << (8 * (r & 3));
                     p = 1.0 - e;
                     q = (x == 'N') ? p : e / B.mismatch_divisor;
                     t4 = B.err_prob[del_byte_at(B, ro + i - 1) & 127u];
@@ -1498,44 +1507,65 @@ __device__ __forceinline__ void run_long_pair(const DeviceBatch& B, const RerunP
         w.Iout = 0.0;
         w.Sd[0] = shr1(w.Sout);  // the first lane of a chunk below the first: the row above it is a read row, whose column 0 holds nothing
         const int steps = H + kWave - 1;
-        for (int s = 0; s < steps; ++s) {
-            T Sin = shr1(w.Sout);
-            T Iin = shr1(w.Iout);
-            const int j = s - lane;  // this lane's column (0-based haplotype position)
-            const bool in_hap = used && j >= 0 && j < H;
-            if (chunk > 0 && lane == 0 && in_hap) {
-                Sin = __hip_atomic_load(above + 2 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                Iin = __hip_atomic_load(above + 2 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Blocks of 64 steps.  Lane 0 of a chunk below the first takes its hand-off from the boundary row: the 64
+        // columns of a block are fetched by the 64 lanes one block ahead of their use and passed through LDS.
+        auto fetch = [&](const int s0, double2& v) {
+            const int j = s0 + lane;
+            v = double2{0.0, 0.0};
+            if (from_above && j < H) {
+                v.x = __hip_atomic_load(above + 2 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v.y = __hip_atomic_load(above + 2 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (in_hap) {
-                const unsigned y = hb[j];
-                T prior[K];
+        };
+        double2 ahead;
+        fetch(0, ahead);
+        unsigned y_next = hb[min(max(-lane, 0), H - 1)];
+        for (int s0 = 0; s0 < steps; s0 += kWave) {
+            __syncthreads();  // the block before has been read
+            stage[lane] = ahead;
+            __syncthreads();
+            fetch(s0 + kWave, ahead);
+            const int block_end = min(s0 + kWave, steps);
+            for (int s = s0; s < block_end; ++s) {
+                T Sin = shr1(w.Sout);
+                T Iin = shr1(w.Iout);
+                const int j = s - lane;  // this lane's column (0-based haplotype position)
+                const bool in_hap = used && j >= 0 && j < H;
+                const unsigned y = y_next;
+                y_next = hb[min(max(j + 1, 0), H - 1)];
+                const double2 handed = stage[s - s0];  // one address for the wave
+                if (from_above && lane == 0) {
+                    Sin = handed.x;
+                    Iin = handed.y;
+                }
+                if (in_hap) {
+                    T prior[K];
 #pragma unroll
-                for (int r = 0; r < K; ++r) prior[r] = (xb[r] == y || y == 'N') ? P[r] : Q[r];  // a read 'N' has Q = P
-                column<T, K>(w, prior, Sin, Iin);
-                if (lane == kWave - 1 && chunk + 1 < chunks) {
-                    __hip_atomic_store(below + 2 * j, w.Sout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(below + 2 * j + 1, w.Iout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int r = 0; r < K; ++r) prior[r] = (((xw[r >> 2] >> (8 * (r & 3))) & 0xffu) == y || y == 'N') ? P[r] : Q[r];  // a read 'N' has Q = P
+                    column<T, K>(w, prior, Sin, Iin);
+                    if (lane == kWave - 1 && chunk + 1 < chunks) {
+                        __hip_atomic_store(below + 2 * j, w.Sout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(below + 2 * j + 1, w.Iout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
         }
         if (used && seg_last) total = w.El[K - 1] + w.Ml[K - 1] + w.Sd[K - 1];  // the sum row
         // the chunk below reads what this one has written: every store of the wave is done before its first load
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
     }
     const int last_lane = (total_lanes - 1) & (kWave - 1);
     if (lane == last_lane) B.out[B.read_out_base[pr.read_idx] + pr.hap_local] = ::log10(total) - Scale<T>::kExp2 * 0.30102999566398119521;
+    __syncthreads();  // the next pair overwrites the haplotype
 }
 
-// One wave per block and pair; a block owns two boundary rows.
+// One wave per block, a pair at a time; a block owns two boundary rows.
 __global__ void __launch_bounds__(kWave) fwd_long(const DeviceBatch B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x;
     double* const boundary = B.long_boundary + static_cast<size_t>(blockIdx.x) * 4 * B.long_boundary_stride;
-    for (int p = blockIdx.x; p < B.num_long_pairs; p += gridDim.x) {
-        run_long_pair(B, B.long_pairs[p], boundary, lane);
-        __builtin_amdgcn_wave_barrier();
-    }
+    for (int p = blockIdx.x; p < B.num_long_pairs; p += gridDim.x) run_long_pair(B, B.long_pairs[p], boundary, lds, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1795,9 +1825,10 @@ hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int waves, hipS
 }
 
 // Enqueue the long-read pass (B.long_pairs / num_long_pairs / long_boundary / long_boundary_stride set); waves: one-wave blocks.
-hipError_t launch_long(const DeviceBatch& B, int waves, hipStream_t stream) {
+hipError_t launch_long(const DeviceBatch& B, int waves, int max_hap_len, hipStream_t stream) {
     if (waves <= 0 || B.num_long_pairs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fwd_long, dim3(waves), dim3(kWave), 0, stream, B);
+    const size_t lds = static_cast<size_t>(kLongStageBytes) + ((static_cast<size_t>(max_hap_len) + 15) & ~size_t{15});
+    hipLaunchKernelGGL(fwd_long, dim3(waves), dim3(kWave), lds, stream, B);
     return hipGetLastError();
 }
 

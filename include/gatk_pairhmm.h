@@ -53,6 +53,13 @@ typedef struct gatk_pairhmm_resident gatk_pairhmm_resident; /* a set of region b
  * qualities under BASE_QUALITY_SCORE_THRESHOLD = 18 (pairhmm/PairHMM.java:54) count as
  * MIN_USABLE_Q_SCORE = 6 (QualityUtils.java:57) - the two steps the upstream likelihood engine applies to
  * a read before the PairHMM sees it.
+ *
+ * Limits, each an ILLEGAL_ARGUMENT ("... is too long", the text of PairHMM.java:273-279): a read of more than 32766
+ * bases, a haplotype of more than 16000.  A haplotype of no bases is rejected too (the reference's matrix has no
+ * column for it).  Reads of up to 1022 bases share wavefronts in the fp32 pass (fp64 for the pairs it cannot hold);
+ * a longer read has more rows than one wavefront carries, and each of its pairs is scored by one wavefront in fp64,
+ * 512 rows at a time - the same results, at a fraction of the rate.  A read of no bases scores log10(0) against
+ * every haplotype.
  */
 typedef struct gatk_pairhmm_batch {
     int32_t num_reads;

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from gatk_amd import pairhmm, sharding, synth
+from gatk_amd.batch import Batch
 from gatk_amd.pairhmm import HipLoglessPairHMM
 
 pytestmark = pytest.mark.gpu
@@ -123,6 +124,36 @@ def test_multi_device_handle_options_errors_and_single_pair(multi, oracle, hc_re
     lk = multi.computeReadLikelihoodGivenHaplotypeLog10(hap, bytes(b.read_bases[lo:hi]), b.read_quals[lo:hi], b.ins_gop[lo:hi],
                                                         b.del_gop[lo:hi], b.gcp[lo:hi])
     assert abs(lk - ref(oracle, b)[0, 0]) <= TOL
+
+
+def test_reads_for_the_long_read_pass_on_the_multi_device_handle(hmm, multi, oracle, hc_regions):
+    """Reads of more than 1022 bases in regions that go whole to one engine, and in one large region that is cut by
+    read ranges between the engines: each engine runs its own long-read launch on its share."""
+    rng = np.random.default_rng(31)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    hap = acgt[rng.integers(0, 4, 1500)]
+    def near(start, n):
+        read = hap[start:start + n].copy()
+        read[::41] = acgt[(np.searchsorted(acgt, read[::41]) + 1) % 4]
+        return read
+    lens = [int(x) for x in rng.choice([100, 151, 1023, 1200, 1400], size=400, p=[0.45, 0.45, 0.04, 0.03, 0.03])]
+    lens[0], lens[-1] = 1300, 1250  # a long read at either end of the read ranges
+    reads = [near(int(rng.integers(0, 90)), n) for n in lens]
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    total = int(offsets[-1])
+    haps = [hap, hap[:1450], hap[10:]] * 8
+    hap_offsets = np.concatenate([[0], np.cumsum([len(x) for x in haps])]).astype(np.int32)
+    big = Batch(np.concatenate(reads), rng.integers(10, 40, total).astype(np.uint8), np.full(total, 45, np.uint8),
+                      np.full(total, 45, np.uint8), np.full(total, 10, np.uint8), offsets, np.concatenate(haps), hap_offsets)
+    small = Batch(big.read_bases[:int(offsets[3])], big.read_quals[:int(offsets[3])], big.ins_gop[:int(offsets[3])],
+                        big.del_gop[:int(offsets[3])], big.gcp[:int(offsets[3])], offsets[:4].copy(), big.hap_bases[:int(hap_offsets[3])],
+                        hap_offsets[:4].copy())
+    regions = hc_regions[:20] + [small] + hc_regions[20:40] + [big]
+    got = multi.compute_regions(regions)
+    check_valid(regions, got)
+    check_against_oracle(oracle, regions, got, [3, 20, 41])
+    assert_same(got, hmm.compute_regions(regions))
+    assert_same([multi.compute_batch(big)], [got[41]])
 
 
 def test_whole_genome_shaped_10k_regions_sharded(hmm, multi, oracle, hc_regions):
