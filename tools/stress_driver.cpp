@@ -51,7 +51,8 @@ Region make_region(Rng& g, bool allow_empty) {
     static const char letters[] = "ACGT";
     Region r;
     r.with_ins = g.range(0, 3) != 0; r.with_del = g.range(0, 3) != 0; r.with_gcp = g.range(0, 3) != 0; r.with_mapq = g.range(0, 4) == 0;
-    const int span = g.range(30, 500);
+    const bool long_region = g.range(0, 39) == 0;  // a region with reads of more than 1022 bases: the long-read pass
+    const int span = long_region ? g.range(1100, 1800) : g.range(30, 500);
     std::vector<uint8_t> ref(span);
     for (auto& b : ref) b = letters[g.range(0, 3)];
     const int nh = g.range(1, 20);
@@ -72,7 +73,8 @@ Region make_region(Rng& g, bool allow_empty) {
     const int nr = allow_empty && g.range(0, 15) == 0 ? 0 : g.range(1, 90);
     for (int k = 0; k < nr; ++k) {
         // a region whose reads are all empty is the reference's "READ_MAX_LENGTH must be > 0": keep read 0 non-empty
-        const int len = (k > 0 && g.range(0, 30) == 0) ? 0 : g.range(1, std::min(span, g.range(0, 5) == 0 ? 260 : 151));
+        int len = (k > 0 && g.range(0, 30) == 0) ? 0 : g.range(1, std::min(span, g.range(0, 5) == 0 ? 260 : 151));
+        if (long_region && k % 16 == 1) len = g.range(1023, span);
         const int start = g.range(0, span - std::max(len, 1));
         const bool noisy = g.range(0, 25) == 0;  // many errors at high quality: the fp32 sum underflows
         for (int i = 0; i < len; ++i) {
