@@ -966,7 +966,12 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
         HIP_TRY(launch_prepare(B, !h->force_fp64, streaming, s));
     }
     if (R->num_long_pairs > 0) {
-        // a wave per pair, at most kLongWaves of them at once; each owns two boundary rows of {diagonal term, insertion mass}
+        // A wave per pair, at most kLongWaves of them at once; each owns two boundary rows of {diagonal term, insertion mass}.
+        // On the call's own stream.  (Tried on MI355X and not kept: a stream of its own, so that a call's few long reads
+        // run beside its fp32 pass.  At equal priority nothing overlapped - a wave of this pass needs half a SIMD's
+        // registers, the forward launch refills every slot one of its waves leaves, and the pass started when that
+        // launch had handed out its last work item; on a stream of the highest priority the call did not come back
+        // within three minutes.)
         const int stride = (R->long_hap_max + 63) & ~63;
         const size_t per_wave = 4 * static_cast<size_t>(stride) * sizeof(double);
         const int waves = static_cast<int>(std::min<size_t>({static_cast<size_t>(R->num_long_pairs), static_cast<size_t>(kLongWaves), std::max<size_t>(kLongBoundaryBytes / per_wave, 256)}));

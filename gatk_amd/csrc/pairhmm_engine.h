@@ -285,7 +285,6 @@ struct gatk_pairhmm {
     pairhmm_host::PinnedBuf signal_out;                              // and where such a result lands (coherent pinned memory)
     unsigned done_seq = 0;                             // value the next such download stores there
     int stream_run_divisor = 2;  // a haplotype run of the stream pass is the items still to hand out over this many times the wave slots
-    bool persistent_waves = false;  // the waves of a stream launch take further items from a counter instead of ending after one
     std::vector<uint8_t> group_rows_table;  // rows per lane by longest read of a wave-group when only some values are allowed (empty: all are)
     int64_t per_group_factor = 32;  // calls with at least this many pairs per wave slot choose rows per lane per wave-group
     bool combine_calls = false;  // small compute_likelihoods calls of all threads on this device share the device's dispatcher
