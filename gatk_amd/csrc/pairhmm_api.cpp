@@ -540,7 +540,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     segs.reserve(static_cast<size_t>(total_reads));
     std::vector<int32_t> neg_inf_idx;
     std::vector<RerunPair> long_pairs;  // the pairs of reads too long for a wave-group
-    int long_hap_max = 0;
+    int long_hap_max = 0, long_read_max = 0;
     std::vector<int> order, lens_desc, len_slot;
     std::vector<ReadInfo> read_info(static_cast<size_t>(total_reads));
     std::vector<StreamDesc> stream_descs;
@@ -570,6 +570,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
             if (len > kMaxGroupedReadLen) {  // more rows than a wave holds: every pair of the read goes to the long-read pass
                 for (int a = 0; a < nh; ++a) long_pairs.push_back(RerunPair{rp.read_begin + r, a});
                 long_hap_max = std::max(long_hap_max, rp.hap_max);
+                long_read_max = std::max(long_read_max, len);
             } else if (len > 0) {
                 read_max = std::max(read_max, len);
                 read_min = std::min(read_min, len);
@@ -850,6 +851,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     if (!long_pairs.empty()) memcpy(S + o_long, long_pairs.data(), long_pairs.size() * sizeof(RerunPair));
     R->num_long_pairs = static_cast<int32_t>(long_pairs.size());
     R->long_hap_max = long_hap_max;
+    R->long_read_max = long_read_max;
     R->hap_stream_entries = scur + kStreamBackPad;
     if (R->hap_stream_entries >= (size_t{1} << 31)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "more than 2^31 haplotype bases in one call");
     const double t_planned = now_ms();
@@ -966,20 +968,26 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
         HIP_TRY(launch_prepare(B, !h->force_fp64, streaming, s));
     }
     if (R->num_long_pairs > 0) {
-        // A wave per pair, at most kLongWaves of them at once; each owns two boundary rows of {diagonal term, insertion mass}.
-        // On the call's own stream.  (Tried on MI355X and not kept: a stream of its own, so that a call's few long reads
+        // At most kLongWaves waves at once; a workgroup owns a boundary row of {diagonal term, insertion mass} per wave and
+        // one more.  On the call's own stream.  (Tried on MI355X and not kept: a stream of its own, so that a call's few long reads
         // run beside its fp32 pass.  At equal priority nothing overlapped - a wave of this pass needs half a SIMD's
         // registers, the forward launch refills every slot one of its waves leaves, and the pass started when that
         // launch had handed out its last work item; on a stream of the highest priority the call did not come back
         // within three minutes.)
+        // Few pairs: a workgroup of several waves works on the chunks of one pair at once, as many as bring the launch
+        // up to a wave per SIMD; with enough pairs for that, a wave per pair.
         const int stride = (R->long_hap_max + 63) & ~63;
-        const size_t per_wave = 4 * static_cast<size_t>(stride) * sizeof(double);
-        const int waves = static_cast<int>(std::min<size_t>({static_cast<size_t>(R->num_long_pairs), static_cast<size_t>(kLongWaves), std::max<size_t>(kLongBoundaryBytes / per_wave, 256)}));
-        HIP_TRY(R->d_long_boundary.ensure(static_cast<size_t>(waves) * 4 * static_cast<size_t>(stride) * sizeof(double)));
+        const int chunks = ((R->long_read_max + 1 + 8) / 8 + kWave - 1) / kWave;  // 64 lanes x 8 rows each
+        const int simds = std::max(h->wave_slots / 3, 1);
+        const int waves_per_block = std::max(1, std::min({kLongMaxWaves, chunks, simds / R->num_long_pairs}));
+        const size_t per_block = static_cast<size_t>(waves_per_block + 1) * 2 * static_cast<size_t>(stride) * sizeof(double);
+        const int blocks = static_cast<int>(std::min<size_t>({static_cast<size_t>(R->num_long_pairs), static_cast<size_t>(kLongWaves / waves_per_block),
+                                                               std::max<size_t>(kLongBoundaryBytes / per_block, 32)}));
+        HIP_TRY(R->d_long_boundary.ensure(static_cast<size_t>(blocks) * per_block));
         DeviceBatch Lg = B;
         Lg.long_boundary = R->d_long_boundary.as<double>();
         Lg.long_boundary_stride = stride;
-        HIP_TRY(launch_long(Lg, waves, R->long_hap_max, s));
+        HIP_TRY(launch_long(Lg, blocks, waves_per_block, R->long_hap_max, s));
     }
     if (timing) HIP_TRY(hipEventRecord(ev[1], s));
     auto bucket_args = [&](size_t bi, int mode) {
@@ -1125,6 +1133,8 @@ int digest_counters(gatk_pairhmm* h, gatk_pairhmm_resident* R, const int32_t* co
     R->last_timing = st;
     h->stats = st;
     h->error_region = h->error_read = -1;
+    if (counters[0] & kStallBit)
+        return fail(GATK_PAIRHMM_DEVICE_ERROR, "the long-read pass gave up waiting for a wave of its workgroup; the call's results are not valid");
     if (counters[0] & 3) {
         // which read: the first one (in the call's read order) that had an input error of either kind
         int region = -1, read_in_region = -1;

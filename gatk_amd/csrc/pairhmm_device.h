@@ -178,6 +178,8 @@ struct DeviceBatch {
     const int32_t* abort_word;
 };
 
+constexpr int32_t kStallBit = 8;  // error-word bit: a wave of the long-read pass gave up waiting for its workgroup (a device error)
+constexpr int kLongMaxWaves = 8;  // most waves of a long-read workgroup, which share one pair
 constexpr int32_t kAbortBit = 4;  // error-word bit: a length exceeds what the caller declared, nothing was scored
 
 }  // namespace pairhmm_hip

@@ -1409,19 +1409,34 @@ __global__ void __launch_bounds__(kWave) fwd_pairs(const DeviceBatch B) {
 // ---------------------------------------------------------------------------------------------
 // Long-read pass
 // ---------------------------------------------------------------------------------------------
-// A read of more than 64 x 16 - 2 bases does not fit the rows of one wave.  Its pairs are scored by one wave each, in
-// double and in the plain arithmetic form (as the fp64 pair pass: the reference's operations in linear space with the
-// 2^1020 initial condition), chunk of rows by chunk of rows: a chunk is 64 lanes x kLongRows rows, swept over the whole
+// A read of more than 64 x 16 - 2 bases does not fit the rows of one wave.  Its pairs are scored in double and in the
+// plain arithmetic form (as the fp64 pair pass: the reference's operations in linear space with the 2^1020 initial
+// condition), chunk of rows by chunk of rows: a chunk is 64 lanes x kLongRows rows, swept by one wave over the whole
 // haplotype like any wave-group; what the chunk's last lane hands downwards in every column (the diagonal term and the
 // insertion mass, the two values a lane takes from the lane above it) goes to a boundary row in global memory, and the
 // first lane of the chunk below reads it there in the same column.  Rows are laid out as everywhere else: pad rows in
 // front, the read's rows, the sum row last.  Emission terms come from comparing the bytes (no table: the rows change
-// with every chunk).  A correctness path, not a fast one: such reads are no HaplotypeCaller input.
+// with every chunk).
+//
+// A workgroup of W waves shares a pair: wave w takes chunks w, w + W, ...; chunk c + 1 follows chunk c a few blocks of
+// 64 columns behind, so W chunks are under way at once (with few pairs in a call the time of a pair is what counts;
+// a launch with enough pairs to fill the device uses W = 1).  The chunks of a pair use W + 1 boundary rows in turn:
+// chunk c writes row c mod (W + 1), which chunk c - W, the last reader of that row, has left by then (it ran on the
+// same wave as c).  How far a row has been written is kept in LDS, one counter per row holding
+// (chunk + 1) << 16 | columns written, raised by the writer after every block; a reader waits for its columns.  Every
+// wait ends: chunk 0 waits for nothing, every other chunk only for the chunk before it.  A wait that nevertheless goes on
+// for about half a second gives up and sets kStallBit in the error word (the host reports a device error) so that the
+// grid always drains.
+// A correctness path, not a fast one: such reads are no HaplotypeCaller input.
 constexpr int kLongRows = 8;
 constexpr int kLongStageBytes = kWave * 16;  // one block of boundary columns: {diagonal term, insertion mass} per column
+constexpr int kLongProgressBytes = 64;       // kLongMaxWaves + 1 counters
+constexpr int kLongSpinLimit = 1 << 21;      // waits of a quarter of a microsecond
 
-// lds: [kLongStageBytes: the boundary columns of the current block of 64 steps][the haplotype's bytes]
-__device__ __forceinline__ void run_long_pair(const DeviceBatch& B, const RerunPair pr, double* boundary, unsigned char* lds, const int lane) {
+// stage: this wave's kLongStageBytes of LDS; progress: the workgroup's counters; hb: the haplotype's bytes in LDS
+__device__ __forceinline__ double run_long_chunk(const DeviceBatch& B, const RerunPair pr, const int chunk, const int num_waves,
+                                                 double* boundary, double2* stage, int* progress, const uint8_t* hb, const int lane,
+                                                 bool& stalled) {
     using T = double;
     constexpr int K = kLongRows;
     const int ro = B.read_off[pr.read_idx];
@@ -1432,140 +1447,170 @@ __device__ __forceinline__ void run_long_pair(const DeviceBatch& B, const RerunP
     const int chunks = (total_lanes + kWave - 1) / kWave;
     const T initD = static_cast<T>(::ldexp(1.0, Scale<T>::kExp2) / static_cast<double>(H));
     const int stride = B.long_boundary_stride;
-    double2* const stage = reinterpret_cast<double2*>(lds);
-    uint8_t* const hb = lds + kLongStageBytes;
-    {   // the haplotype into LDS, four bytes a lane (haplotypes start at multiples of 16 in the pool and are padded to one)
-        const uint8_t* const src = B.hap_pool + B.hap_off[hap];
-        for (int j = lane * 4; j < H; j += kWave * 4)
-            *reinterpret_cast<uint32_t*>(hb + j) = *reinterpret_cast<const uint32_t*>(src + j);
-    }
-    __syncthreads();
-    T total = 0.0;
-    for (int chunk = 0; chunk < chunks; ++chunk) {
-        const int g = chunk * kWave + lane;  // this lane's place among all lanes of the pair
-        const bool used = g < total_lanes;
-        const int first_row = g * K + 1 - (total_lanes * K - R - 1);  // pads | rows 1..R | sum row
-        const bool seg_last = g == total_lanes - 1;
-        // what the chunk above left per column, and where this chunk leaves its own: {diagonal term, insertion mass}
-        // (read and written through the device-coherent cache level: the reader is another lane of the same wave, a chunk later)
-        double* const above = boundary + static_cast<size_t>((chunk + 1) & 1) * 2 * stride;
-        double* const below = boundary + static_cast<size_t>(chunk & 1) * 2 * stride;
-        const bool from_above = chunk > 0;
-        Rows<T, K> w;
-        T P[K], Q[K];
-        unsigned xw[K / 4] = {};  // the rows' read bytes, four to a word (0: a row without a base, which no haplotype byte equals)
+    const int g = chunk * kWave + lane;  // this lane's place among all lanes of the pair
+    const bool used = g < total_lanes;
+    const int first_row = g * K + 1 - (total_lanes * K - R - 1);  // pads | rows 1..R | sum row
+    const bool seg_last = g == total_lanes - 1;
+    // what the chunk above left per column, and where this chunk leaves its own: {diagonal term, insertion mass}
+    // (read and written through the device-coherent cache level)
+    const int num_rows = num_waves + 1;
+    const bool from_above = chunk > 0;
+    const bool to_below = chunk + 1 < chunks;
+    const int row_in = (chunk + num_rows - 1) % num_rows, row_out = chunk % num_rows;
+    double* const above = boundary + static_cast<size_t>(row_in) * 2 * stride;
+    double* const below = boundary + static_cast<size_t>(row_out) * 2 * stride;
+    const int tag_in = chunk << 16, tag_out = (chunk + 1) << 16;
+    Rows<T, K> w;
+    T P[K], Q[K];
+    unsigned xw[K / 4] = {};  // the rows' read bytes, four to a word (0: a row without a base, whose terms are equal anyway)
 #pragma unroll
-        for (int r = 0; r < K; ++r) {
-            const int i = first_row + r;
-            double p = 0, q = 0, t4 = 0, t5 = 0, t0n = 0, t1n = 0, t2n = 0, t3n = 0;
-            bool pad = false, has_next = false;
-            const bool sum_row = used && i == R + 1;
-            const bool last_row = used && i == R;
-            if (sum_row) {
-                p = q = 1.0;
+    for (int r = 0; r < K; ++r) {
+        const int i = first_row + r;
+        double p = 0, q = 0, t4 = 0, t5 = 0, t0n = 0, t1n = 0, t2n = 0, t3n = 0;
+        bool pad = false, has_next = false;
+        const bool sum_row = used && i == R + 1;
+        const bool last_row = used && i == R;
+        if (sum_row) {
+            p = q = 1.0;
+            t5 = 1.0;
+        } else if (used) {
+            if (i >= 1) {
+                const unsigned x = B.read_bases[ro + i - 1];
+                const double e = B.err_prob[effective_qual(B, ro + i - 1, pr.read_idx)];
+                xw[r >> 2] |= x << (8 * (r & 3));
+                p = 1.0 - e;
+                q = (x == 'N') ? p : e / B.mismatch_divisor;
+                t4 = B.err_prob[del_byte_at(B, ro + i - 1) & 127u];
+                t5 = B.err_prob[gcp_byte_at(B, ro + i - 1)];
+            } else {
+                pad = true;
+                t4 = 1.0;
                 t5 = 1.0;
-            } else if (used) {
-                if (i >= 1) {
-                    const unsigned x = B.read_bases[ro + i - 1];
-                    const double e = B.err_prob[effective_qual(B, ro + i - 1, pr.read_idx)];
-                    xw[r >> 2] |= x << (8 * (r & 3));
-                    p = 1.0 - e;
-                    q = (x == 'N') ? p : e / B.mismatch_divisor;
-                    t4 = B.err_prob[del_byte_at(B, ro + i - 1) & 127u];
-                    t5 = B.err_prob[gcp_byte_at(B, ro + i - 1)];
-                } else {
-                    pad = true;
-                    t4 = 1.0;
-                    t5 = 1.0;
-                    if (i < 0) t1n = 1.0;
-                }
-                if (i >= 0 && i < R) {
-                    const unsigned ins = ins_byte_at(B, ro + i) & 127u, del = del_byte_at(B, ro + i) & 127u;
-                    const double eg = B.err_prob[gcp_byte_at(B, ro + i)];
-                    has_next = true;
-                    t0n = B.match_to_match[ins * 128u + del];
-                    t1n = 1.0 - eg;
-                    t2n = B.err_prob[ins];
-                    t3n = eg;
-                }
+                if (i < 0) t1n = 1.0;
             }
-            const bool real_next = has_next && i >= 1;
-            P[r] = p;
-            Q[r] = q;
-            w.T5[r] = t5;
-            w.A[r] = real_next ? t0n : last_row ? 1.0 : 0.0;
-            w.B[r] = last_row ? 1.0 : t1n;
-            w.C[r] = real_next ? t2n : 0.0;
-            w.D[r] = real_next ? t3n : 0.0;
-            w.E[r] = t4 * t1n;
-            w.Ml[r] = 0.0;
-            w.El[r] = pad ? initD : 0.0;  // column 0
-        }
-#pragma unroll
-        for (int r = 1; r < K; ++r) w.Sd[r] = w.El[r - 1] * w.E[r - 1];
-        w.Sout = w.El[K - 1] * w.E[K - 1];
-        w.Iout = 0.0;
-        w.Sd[0] = shr1(w.Sout);  // the first lane of a chunk below the first: the row above it is a read row, whose column 0 holds nothing
-        const int steps = H + kWave - 1;
-        // Blocks of 64 steps.  Lane 0 of a chunk below the first takes its hand-off from the boundary row: the 64
-        // columns of a block are fetched by the 64 lanes one block ahead of their use and passed through LDS.
-        auto fetch = [&](const int s0, double2& v) {
-            const int j = s0 + lane;
-            v = double2{0.0, 0.0};
-            if (from_above && j < H) {
-                v.x = __hip_atomic_load(above + 2 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v.y = __hip_atomic_load(above + 2 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        };
-        double2 ahead;
-        fetch(0, ahead);
-        unsigned y_next = hb[min(max(-lane, 0), H - 1)];
-        for (int s0 = 0; s0 < steps; s0 += kWave) {
-            __syncthreads();  // the block before has been read
-            stage[lane] = ahead;
-            __syncthreads();
-            fetch(s0 + kWave, ahead);
-            const int block_end = min(s0 + kWave, steps);
-            for (int s = s0; s < block_end; ++s) {
-                T Sin = shr1(w.Sout);
-                T Iin = shr1(w.Iout);
-                const int j = s - lane;  // this lane's column (0-based haplotype position)
-                const bool in_hap = used && j >= 0 && j < H;
-                const unsigned y = y_next;
-                y_next = hb[min(max(j + 1, 0), H - 1)];
-                const double2 handed = stage[s - s0];  // one address for the wave
-                if (from_above && lane == 0) {
-                    Sin = handed.x;
-                    Iin = handed.y;
-                }
-                if (in_hap) {
-                    T prior[K];
-#pragma unroll
-                    for (int r = 0; r < K; ++r) prior[r] = (((xw[r >> 2] >> (8 * (r & 3))) & 0xffu) == y || y == 'N') ? P[r] : Q[r];  // a read 'N' has Q = P
-                    column<T, K>(w, prior, Sin, Iin);
-                    if (lane == kWave - 1 && chunk + 1 < chunks) {
-                        __hip_atomic_store(below + 2 * j, w.Sout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(below + 2 * j + 1, w.Iout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
+            if (i >= 0 && i < R) {
+                const unsigned ins = ins_byte_at(B, ro + i) & 127u, del = del_byte_at(B, ro + i) & 127u;
+                const double eg = B.err_prob[gcp_byte_at(B, ro + i)];
+                has_next = true;
+                t0n = B.match_to_match[ins * 128u + del];
+                t1n = 1.0 - eg;
+                t2n = B.err_prob[ins];
+                t3n = eg;
             }
         }
-        if (used && seg_last) total = w.El[K - 1] + w.Ml[K - 1] + w.Sd[K - 1];  // the sum row
-        // the chunk below reads what this one has written: every store of the wave is done before its first load
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-        __syncthreads();
+        const bool real_next = has_next && i >= 1;
+        P[r] = p;
+        Q[r] = q;
+        w.T5[r] = t5;
+        w.A[r] = real_next ? t0n : last_row ? 1.0 : 0.0;
+        w.B[r] = last_row ? 1.0 : t1n;
+        w.C[r] = real_next ? t2n : 0.0;
+        w.D[r] = real_next ? t3n : 0.0;
+        w.E[r] = t4 * t1n;
+        w.Ml[r] = 0.0;
+        w.El[r] = pad ? initD : 0.0;  // column 0
     }
-    const int last_lane = (total_lanes - 1) & (kWave - 1);
-    if (lane == last_lane) B.out[B.read_out_base[pr.read_idx] + pr.hap_local] = ::log10(total) - Scale<T>::kExp2 * 0.30102999566398119521;
-    __syncthreads();  // the next pair overwrites the haplotype
+#pragma unroll
+    for (int r = 1; r < K; ++r) w.Sd[r] = w.El[r - 1] * w.E[r - 1];
+    w.Sout = w.El[K - 1] * w.E[K - 1];
+    w.Iout = 0.0;
+    w.Sd[0] = shr1(w.Sout);  // the first lane of a chunk below the first: the row above it is a read row, whose column 0 holds nothing
+    const int steps = H + kWave - 1;
+    // Blocks of 64 steps.  Lane 0 of a chunk below the first takes its hand-off from the boundary row: the 64
+    // columns of a block are fetched by the 64 lanes one block ahead of their use and passed through LDS.
+    auto fetch = [&](const int s0, double2& v) {
+        v = double2{0.0, 0.0};
+        if (!from_above || s0 >= H) return;  // wave-uniform
+        const int need = tag_in + min(s0 + kWave, H);
+        for (int spins = 0; __hip_atomic_load(progress + row_in, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need; ++spins) {
+            if (spins > kLongSpinLimit) { stalled = true; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        const int j = s0 + lane;
+        if (j < H) {
+            v.x = __hip_atomic_load(above + 2 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v.y = __hip_atomic_load(above + 2 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    double2 ahead;
+    fetch(0, ahead);
+    unsigned y_next = hb[min(max(-lane, 0), H - 1)];
+    for (int s0 = 0; s0 < steps; s0 += kWave) {
+        // this wave's lanes only: LDS serves a wave's reads and writes in the order it issued them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        stage[lane] = ahead;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        fetch(s0 + kWave, ahead);
+        const int block_end = min(s0 + kWave, steps);
+        for (int s = s0; s < block_end; ++s) {
+            T Sin = shr1(w.Sout);
+            T Iin = shr1(w.Iout);
+            const int j = s - lane;  // this lane's column (0-based haplotype position)
+            const bool in_hap = used && j >= 0 && j < H;
+            const unsigned y = y_next;
+            y_next = hb[min(max(j + 1, 0), H - 1)];
+            const double2 handed = stage[s - s0];  // one address for the wave
+            if (from_above && lane == 0) {
+                Sin = handed.x;
+                Iin = handed.y;
+            }
+            if (in_hap) {
+                T prior[K];
+#pragma unroll
+                for (int r = 0; r < K; ++r) prior[r] = (((xw[r >> 2] >> (8 * (r & 3))) & 0xffu) == y || y == 'N') ? P[r] : Q[r];  // a read 'N' has Q = P
+                column<T, K>(w, prior, Sin, Iin);
+                if (lane == kWave - 1 && to_below) {
+                    __hip_atomic_store(below + 2 * j, w.Sout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(below + 2 * j + 1, w.Iout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (to_below) {  // the last lane has finished the columns up to block_end - 64: its stores first, then the count
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) __hip_atomic_store(progress + row_out, tag_out + min(max(block_end - (kWave - 1), 0), H), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    T total = 0.0;
+    if (used && seg_last) total = w.El[K - 1] + w.Ml[K - 1] + w.Sd[K - 1];  // the sum row
+    return total;
 }
 
-// One wave per block, a pair at a time; a block owns two boundary rows.
-__global__ void __launch_bounds__(kWave) fwd_long(const DeviceBatch B) {
+// Workgroups of 1 to kLongMaxWaves waves, a pair at a time; a workgroup owns waves + 1 boundary rows.
+// Dynamic LDS: [waves x kLongStageBytes][kLongProgressBytes][the longest haplotype's bytes, rounded up to 16].
+__global__ void __launch_bounds__(kWave* kLongMaxWaves) fwd_long(const DeviceBatch B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int lane = threadIdx.x;
-    double* const boundary = B.long_boundary + static_cast<size_t>(blockIdx.x) * 4 * B.long_boundary_stride;
-    for (int p = blockIdx.x; p < B.num_long_pairs; p += gridDim.x) run_long_pair(B, B.long_pairs[p], boundary, lds, lane);
+    const int num_waves = static_cast<int>(blockDim.x) >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
+    const int lane = threadIdx.x & (kWave - 1);
+    double* const boundary = B.long_boundary + static_cast<size_t>(blockIdx.x) * (num_waves + 1) * 2 * B.long_boundary_stride;
+    double2* const stage = reinterpret_cast<double2*>(lds + wave * kLongStageBytes);
+    int* const progress = reinterpret_cast<int*>(lds + num_waves * kLongStageBytes);
+    uint8_t* const hb = lds + num_waves * kLongStageBytes + kLongProgressBytes;
+    bool stalled = false;
+    for (int p = blockIdx.x; p < B.num_long_pairs; p += gridDim.x) {
+        const RerunPair pr = B.long_pairs[p];
+        const int hap = B.read_info[pr.read_idx].hap_begin + pr.hap_local;
+        const int H = B.hap_len[hap];
+        const int R = B.read_off[pr.read_idx + 1] - B.read_off[pr.read_idx];
+        const int total_lanes = (R + 1 + kLongRows) / kLongRows;
+        const int chunks = (total_lanes + kWave - 1) / kWave;
+        {   // the haplotype into LDS, four bytes a thread (haplotypes start at multiples of 16 in the pool and are padded to one)
+            const uint8_t* const src = B.hap_pool + B.hap_off[hap];
+            for (int j = threadIdx.x * 4; j < H; j += blockDim.x * 4)
+                *reinterpret_cast<uint32_t*>(hb + j) = *reinterpret_cast<const uint32_t*>(src + j);
+        }
+        if (threadIdx.x <= static_cast<unsigned>(num_waves)) progress[threadIdx.x] = 0;
+        __syncthreads();
+        for (int chunk = wave; chunk < chunks; chunk += num_waves) {
+            const double total = run_long_chunk(B, pr, chunk, num_waves, boundary, stage, progress, hb, lane, stalled);
+            if (chunk == chunks - 1 && lane == ((total_lanes - 1) & (kWave - 1)))
+                B.out[B.read_out_base[pr.read_idx] + pr.hap_local] = ::log10(total) - Scale<double>::kExp2 * 0.30102999566398119521;
+        }
+        __syncthreads();  // the next pair overwrites the haplotype and the counters
+    }
+    if (stalled && lane == 0) report_input_error(B, kStallBit, -1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1825,10 +1870,14 @@ hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int waves, hipS
 }
 
 // Enqueue the long-read pass (B.long_pairs / num_long_pairs / long_boundary / long_boundary_stride set); waves: one-wave blocks.
-hipError_t launch_long(const DeviceBatch& B, int waves, int max_hap_len, hipStream_t stream) {
-    if (waves <= 0 || B.num_long_pairs <= 0) return hipSuccess;
-    const size_t lds = static_cast<size_t>(kLongStageBytes) + ((static_cast<size_t>(max_hap_len) + 15) & ~size_t{15});
-    hipLaunchKernelGGL(fwd_long, dim3(waves), dim3(kWave), lds, stream, B);
+int long_lds_bytes(int waves_per_block, int max_hap_len) {
+    return waves_per_block * kLongStageBytes + kLongProgressBytes + ((max_hap_len + 15) & ~15);
+}
+
+hipError_t launch_long(const DeviceBatch& B, int blocks, int waves_per_block, int max_hap_len, hipStream_t stream) {
+    if (blocks <= 0 || B.num_long_pairs <= 0) return hipSuccess;
+    if (waves_per_block < 1 || waves_per_block > kLongMaxWaves) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fwd_long, dim3(blocks), dim3(kWave * waves_per_block), static_cast<size_t>(long_lds_bytes(waves_per_block, max_hap_len)), stream, B);
     return hipGetLastError();
 }
 

@@ -57,8 +57,8 @@ typedef struct gatk_pairhmm_resident gatk_pairhmm_resident; /* a set of region b
  * Limits, each an ILLEGAL_ARGUMENT ("... is too long", the text of PairHMM.java:273-279): a read of more than 32766
  * bases, a haplotype of more than 16000.  A haplotype of no bases is rejected too (the reference's matrix has no
  * column for it).  Reads of up to 1022 bases share wavefronts in the fp32 pass (fp64 for the pairs it cannot hold);
- * a longer read has more rows than one wavefront carries, and each of its pairs is scored by one wavefront in fp64,
- * 512 rows at a time - the same results, at a fraction of the rate.  A read of no bases scores log10(0) against
+ * a longer read has more rows than one wavefront carries, and each of its pairs is scored in fp64, 512 rows at a
+ * time, by one to eight wavefronts - the same results, at a fraction of the rate.  A read of no bases scores log10(0) against
  * every haplotype.
  */
 typedef struct gatk_pairhmm_batch {

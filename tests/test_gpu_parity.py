@@ -223,6 +223,25 @@ def test_reads_longer_than_a_wave_holds(hmm, oracle, length):
         hmm.set_option("force_fp64", 0)
 
 
+@pytest.mark.parametrize("num_haps", [150, 300, 400, 600])
+def test_long_read_workgroups_of_every_size(hmm, oracle, num_haps):
+    """The waves of a long-read workgroup share a pair's chunks of rows, and the fewer pairs a call has the more waves
+    a workgroup gets: one read of 1600 bases (four chunks) against 150, 300, 400 and 600 haplotypes runs with four,
+    three, two and one wave per pair - with three and two the boundary rows are reused within a pair."""
+    rng = np.random.default_rng(7600 + num_haps)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    hap = acgt[rng.integers(0, 4, 1700)]
+    haps = []
+    for a in range(num_haps):
+        x = hap[:1700 - a % 7].copy()
+        x[3 * a % 1600] = acgt[(np.searchsorted(acgt, x[3 * a % 1600]) + 1) % 4]
+        haps.append(x)
+    b = pack([(_near_copy(rng, hap, 30, 1600), rng.integers(10, 40, 1600), None, None, None)], haps)
+    want = ref(oracle, b)
+    assert np.isfinite(want).all()
+    assert_parity(hmm.compute_batch(b), want, tol=1e-9)
+
+
 def test_long_reads_among_ordinary_ones(hmm, oracle):
     """Reads for the long-read pass, ordinary reads, a read of exactly 1022 bases (the longest a wave-group takes) and
     a zero-length read in one region, next to a region of ordinary reads and one that holds a long read only: every
