@@ -306,6 +306,14 @@ def other_configs(device, hc_regions):
         st = hmm.stats()
         out["c5"]["fp64_rerun"] = {"pairs": st["rerun_pairs"], "rate": round(st["rerun_pairs"] / max(call.pairs, 1), 6)}
         out["c5"]["kernels"] = kernel_split(device, c5)
+        try:  # reads with more rows than a wave holds: the fp64 long-read pass (no HaplotypeCaller input; reported for completeness)
+            long_reads = synth.make_batch(256, 16, 2000, 2200, seed=11)
+            call = HostCall(hmm, [long_reads], True)
+            out["long_reads"] = leg(call, 3, "256 reads (2000 bp) x 16 haplotypes (2200 bp): every pair through the fp64 long-read pass")
+            out["long_reads"]["roofline_frac"] = roof_frac(call.cells, out["long_reads"]["wall_ms"] * 1e-3, PEAK_FP64_VALU_TFLOPS)
+            out["long_reads"]["roofline_peak_tflops"] = PEAK_FP64_VALU_TFLOPS
+        except Exception as e:  # never lose the line over the extra leg
+            out["long_reads"] = {"error": repr(e)}
         call = HostCall(hmm, hc_regions, False)
         out["hc_2000_regions"] = leg(call, 8, f"HaplotypeCaller-shaped stream, {len(hc_regions)} active regions (30x, 121-151 bp reads, 2-32 "
                                               "haplotypes of 250-500 bp) in one compute_regions call")
