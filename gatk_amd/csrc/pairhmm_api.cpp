@@ -852,6 +852,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     R->num_long_pairs = static_cast<int32_t>(long_pairs.size());
     R->long_hap_max = long_hap_max;
     R->long_read_max = long_read_max;
+    R->haps_acgtn_only = !any_hap_other;
     R->hap_stream_entries = scur + kStreamBackPad;
     if (R->hap_stream_entries >= (size_t{1} << 31)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "more than 2^31 haplotype bases in one call");
     const double t_planned = now_ms();
@@ -987,7 +988,14 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
         DeviceBatch Lg = B;
         Lg.long_boundary = R->d_long_boundary.as<double>();
         Lg.long_boundary_stride = stride;
-        HIP_TRY(launch_long(Lg, blocks, waves_per_block, R->long_hap_max, s));
+        // Emission terms from a per-wave LDS table (a quarter faster per wave, but 20 KiB of LDS a wave: six waves on a CU
+        // instead of eight) when every pair of the call is resident at once even so; byte compares otherwise.
+        bool table = R->haps_acgtn_only && h->emit_mode != 0 && long_table_fits(waves_per_block);
+        if (table) {
+            const int per_cu = std::min((160 * 1024) / long_lds_bytes(waves_per_block, R->long_hap_max, true), 8 / waves_per_block);
+            table = R->num_long_pairs <= per_cu * (simds / 4);
+        }
+        HIP_TRY(launch_long(Lg, blocks, waves_per_block, R->long_hap_max, table, s));
     }
     if (timing) HIP_TRY(hipEventRecord(ev[1], s));
     auto bucket_args = [&](size_t bi, int mode) {

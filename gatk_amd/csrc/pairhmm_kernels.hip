@@ -1433,10 +1433,13 @@ constexpr int kLongStageBytes = kWave * 16;  // one block of boundary columns: {
 constexpr int kLongProgressBytes = 64;       // kLongMaxWaves + 1 counters
 constexpr int kLongSpinLimit = 1 << 21;      // waits of a quarter of a microsecond
 
-// stage: this wave's kLongStageBytes of LDS; progress: the workgroup's counters; hb: the haplotype's bytes in LDS
+// stage: this wave's kLongStageBytes of LDS; progress: the workgroup's counters; hb: the haplotype in LDS, its bytes or,
+// with a table, its base codes; table: this wave's emission table in LDS, as the fp64 pair pass lays it out
+// ([row pair][base code][lane][2] doubles), written anew for every chunk.
+template <bool kTable>
 __device__ __forceinline__ double run_long_chunk(const DeviceBatch& B, const RerunPair pr, const int chunk, const int num_waves,
-                                                 double* boundary, double2* stage, int* progress, const uint8_t* hb, const int lane,
-                                                 bool& stalled) {
+                                                 double* boundary, double2* stage, int* progress, const uint8_t* hb, unsigned char* table,
+                                                 const int lane, bool& stalled) {
     using T = double;
     constexpr int K = kLongRows;
     const int ro = B.read_off[pr.read_idx];
@@ -1461,13 +1464,20 @@ __device__ __forceinline__ double run_long_chunk(const DeviceBatch& B, const Rer
     double* const below = boundary + static_cast<size_t>(row_out) * 2 * stride;
     const int tag_in = chunk << 16, tag_out = (chunk + 1) << 16;
     Rows<T, K> w;
-    T P[K], Q[K];
+    T P[K], Q[K];             // compare mode only
     unsigned xw[K / 4] = {};  // the rows' read bytes, four to a word (0: a row without a base, whose terms are equal anyway)
+    const unsigned letters[kPairCodes] = {'A', 'C', 'T', 'G', 'N'};
+    double* const tbl = reinterpret_cast<double*>(table);
+    if constexpr (kTable) {  // the table of the chunk before has been read to the end
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 #pragma unroll
     for (int r = 0; r < K; ++r) {
         const int i = first_row + r;
         double p = 0, q = 0, t4 = 0, t5 = 0, t0n = 0, t1n = 0, t2n = 0, t3n = 0;
         bool pad = false, has_next = false;
+        unsigned xb = kNoBase;
         const bool sum_row = used && i == R + 1;
         const bool last_row = used && i == R;
         if (sum_row) {
@@ -1478,6 +1488,7 @@ __device__ __forceinline__ double run_long_chunk(const DeviceBatch& B, const Rer
                 const unsigned x = B.read_bases[ro + i - 1];
                 const double e = B.err_prob[effective_qual(B, ro + i - 1, pr.read_idx)];
                 xw[r >> 2] |= x << (8 * (r & 3));
+                xb = x;
                 p = 1.0 - e;
                 q = (x == 'N') ? p : e / B.mismatch_divisor;
                 t4 = B.err_prob[del_byte_at(B, ro + i - 1) & 127u];
@@ -1499,8 +1510,14 @@ __device__ __forceinline__ double run_long_chunk(const DeviceBatch& B, const Rer
             }
         }
         const bool real_next = has_next && i >= 1;
-        P[r] = p;
-        Q[r] = q;
+        if constexpr (kTable) {
+#pragma unroll
+            for (int cd = 0; cd < kPairCodes; ++cd)  // a haplotype 'N' matches every row, a read 'N' (q = p) every column
+                tbl[(((r >> 1) * kPairCodes + cd) * kWave + lane) * 2 + (r & 1)] = (xb == letters[cd] || cd == 4) ? p : q;
+        } else {
+            P[r] = p;
+            Q[r] = q;
+        }
         w.T5[r] = t5;
         w.A[r] = real_next ? t0n : last_row ? 1.0 : 0.0;
         w.B[r] = last_row ? 1.0 : t1n;
@@ -1516,6 +1533,24 @@ __device__ __forceinline__ double run_long_chunk(const DeviceBatch& B, const Rer
     w.Iout = 0.0;
     w.Sd[0] = shr1(w.Sout);  // the first lane of a chunk below the first: the row above it is a read row, whose column 0 holds nothing
     const int steps = H + kWave - 1;
+    const unsigned char* const tbl_lane = table + lane * 16;
+    auto emit = [&](const unsigned y, T (&prior)[K]) {  // y: a haplotype byte, or with a table its base code
+        if constexpr (kTable) {
+#pragma unroll
+            for (int g2 = 0; g2 < K / 2; ++g2) {
+                const double2 v = *reinterpret_cast<const double2*>(tbl_lane + y * kLutCodeStride + g2 * kPairCodes * kLutCodeStride);
+                prior[2 * g2] = v.x;
+                prior[2 * g2 + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < K; ++r) prior[r] = (((xw[r >> 2] >> (8 * (r & 3))) & 0xffu) == y || y == 'N') ? P[r] : Q[r];  // a read 'N' has Q = P
+        }
+    };
+    if constexpr (kTable) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     // Blocks of 64 steps.  Lane 0 of a chunk below the first takes its hand-off from the boundary row: the 64
     // columns of a block are fetched by the 64 lanes one block ahead of their use and passed through LDS.
     auto fetch = [&](const int s0, double2& v) {
@@ -1558,8 +1593,7 @@ __device__ __forceinline__ double run_long_chunk(const DeviceBatch& B, const Rer
             }
             if (in_hap) {
                 T prior[K];
-#pragma unroll
-                for (int r = 0; r < K; ++r) prior[r] = (((xw[r >> 2] >> (8 * (r & 3))) & 0xffu) == y || y == 'N') ? P[r] : Q[r];  // a read 'N' has Q = P
+                emit(y, prior);
                 column<T, K>(w, prior, Sin, Iin);
                 if (lane == kWave - 1 && to_below) {
                     __hip_atomic_store(below + 2 * j, w.Sout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1578,7 +1612,14 @@ __device__ __forceinline__ double run_long_chunk(const DeviceBatch& B, const Rer
 }
 
 // Workgroups of 1 to kLongMaxWaves waves, a pair at a time; a workgroup owns waves + 1 boundary rows.
-// Dynamic LDS: [waves x kLongStageBytes][kLongProgressBytes][the longest haplotype's bytes, rounded up to 16].
+// Dynamic LDS: [waves x kLongStageBytes][kLongProgressBytes][with a table: waves x kLongTableBytes][the longest
+// haplotype's bytes, rounded up to 16].  kTable: emission terms from a per-wave table instead of comparing bytes, a third
+// fewer vector instructions per step; for launches of one or two waves per workgroup (the table is 20 KiB a wave)
+// whose haplotypes hold A, C, G, T and N only.
+constexpr int kLongTableBytes = pair_table_bytes(kLongRows);
+constexpr int kLongTableMaxWaves = 2;
+
+template <bool kTable>
 __global__ void __launch_bounds__(kWave* kLongMaxWaves) fwd_long(const DeviceBatch B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int num_waves = static_cast<int>(blockDim.x) >> 6;
@@ -1587,7 +1628,8 @@ __global__ void __launch_bounds__(kWave* kLongMaxWaves) fwd_long(const DeviceBat
     double* const boundary = B.long_boundary + static_cast<size_t>(blockIdx.x) * (num_waves + 1) * 2 * B.long_boundary_stride;
     double2* const stage = reinterpret_cast<double2*>(lds + wave * kLongStageBytes);
     int* const progress = reinterpret_cast<int*>(lds + num_waves * kLongStageBytes);
-    uint8_t* const hb = lds + num_waves * kLongStageBytes + kLongProgressBytes;
+    unsigned char* const tables = lds + num_waves * kLongStageBytes + kLongProgressBytes;
+    uint8_t* const hb = tables + (kTable ? num_waves * kLongTableBytes : 0);
     bool stalled = false;
     for (int p = blockIdx.x; p < B.num_long_pairs; p += gridDim.x) {
         const RerunPair pr = B.long_pairs[p];
@@ -1598,13 +1640,24 @@ __global__ void __launch_bounds__(kWave* kLongMaxWaves) fwd_long(const DeviceBat
         const int chunks = (total_lanes + kWave - 1) / kWave;
         {   // the haplotype into LDS, four bytes a thread (haplotypes start at multiples of 16 in the pool and are padded to one)
             const uint8_t* const src = B.hap_pool + B.hap_off[hap];
-            for (int j = threadIdx.x * 4; j < H; j += blockDim.x * 4)
-                *reinterpret_cast<uint32_t*>(hb + j) = *reinterpret_cast<const uint32_t*>(src + j);
+            for (int j = threadIdx.x * 4; j < H; j += blockDim.x * 4) {
+                uint32_t four = *reinterpret_cast<const uint32_t*>(src + j);
+                if constexpr (kTable) {  // bytes -> base codes, the order of the table's columns: A C T G N
+                    uint32_t codes = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t byte = (four >> (8 * k)) & 0xffu;
+                        codes |= (byte == 'N' ? 4u : ((byte >> 1) & 3u)) << (8 * k);
+                    }
+                    four = codes;
+                }
+                *reinterpret_cast<uint32_t*>(hb + j) = four;
+            }
         }
         if (threadIdx.x <= static_cast<unsigned>(num_waves)) progress[threadIdx.x] = 0;
         __syncthreads();
         for (int chunk = wave; chunk < chunks; chunk += num_waves) {
-            const double total = run_long_chunk(B, pr, chunk, num_waves, boundary, stage, progress, hb, lane, stalled);
+            const double total = run_long_chunk<kTable>(B, pr, chunk, num_waves, boundary, stage, progress, hb, tables + wave * kLongTableBytes, lane, stalled);
             if (chunk == chunks - 1 && lane == ((total_lanes - 1) & (kWave - 1)))
                 B.out[B.read_out_base[pr.read_idx] + pr.hap_local] = ::log10(total) - Scale<double>::kExp2 * 0.30102999566398119521;
         }
@@ -1870,14 +1923,18 @@ hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int waves, hipS
 }
 
 // Enqueue the long-read pass (B.long_pairs / num_long_pairs / long_boundary / long_boundary_stride set); waves: one-wave blocks.
-int long_lds_bytes(int waves_per_block, int max_hap_len) {
-    return waves_per_block * kLongStageBytes + kLongProgressBytes + ((max_hap_len + 15) & ~15);
+bool long_table_fits(int waves_per_block) { return waves_per_block <= kLongTableMaxWaves; }
+
+int long_lds_bytes(int waves_per_block, int max_hap_len, bool table) {
+    return waves_per_block * kLongStageBytes + kLongProgressBytes + (table ? waves_per_block * kLongTableBytes : 0) + ((max_hap_len + 15) & ~15);
 }
 
-hipError_t launch_long(const DeviceBatch& B, int blocks, int waves_per_block, int max_hap_len, hipStream_t stream) {
+hipError_t launch_long(const DeviceBatch& B, int blocks, int waves_per_block, int max_hap_len, bool table, hipStream_t stream) {
     if (blocks <= 0 || B.num_long_pairs <= 0) return hipSuccess;
-    if (waves_per_block < 1 || waves_per_block > kLongMaxWaves) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fwd_long, dim3(blocks), dim3(kWave * waves_per_block), static_cast<size_t>(long_lds_bytes(waves_per_block, max_hap_len)), stream, B);
+    if (waves_per_block < 1 || waves_per_block > kLongMaxWaves || (table && !long_table_fits(waves_per_block))) return hipErrorInvalidValue;
+    const size_t lds = static_cast<size_t>(long_lds_bytes(waves_per_block, max_hap_len, table));
+    if (table) hipLaunchKernelGGL(fwd_long<true>, dim3(blocks), dim3(kWave * waves_per_block), lds, stream, B);
+    else hipLaunchKernelGGL(fwd_long<false>, dim3(blocks), dim3(kWave * waves_per_block), lds, stream, B);
     return hipGetLastError();
 }
 

@@ -227,7 +227,9 @@ def test_reads_longer_than_a_wave_holds(hmm, oracle, length):
 def test_long_read_workgroups_of_every_size(hmm, oracle, num_haps):
     """The waves of a long-read workgroup share a pair's chunks of rows, and the fewer pairs a call has the more waves
     a workgroup gets: one read of 1600 bases (four chunks) against 150, 300, 400 and 600 haplotypes runs with four,
-    three, two and one wave per pair - with three and two the boundary rows are reused within a pair."""
+    three, two and one wave per pair - with three and two the boundary rows are reused within a pair.  Workgroups of
+    one and two waves take their emission terms from a table in LDS when all pairs are on the device at once, and
+    compare bytes like the larger ones when the engine is told to (emit_mode 0) or a haplotype holds another letter."""
     rng = np.random.default_rng(7600 + num_haps)
     acgt = np.frombuffer(b"ACGT", np.uint8)
     hap = acgt[rng.integers(0, 4, 1700)]
@@ -240,6 +242,15 @@ def test_long_read_workgroups_of_every_size(hmm, oracle, num_haps):
     want = ref(oracle, b)
     assert np.isfinite(want).all()
     assert_parity(hmm.compute_batch(b), want, tol=1e-9)
+    hmm.set_option("emit_mode", 0)
+    try:
+        assert_parity(hmm.compute_batch(b), want, tol=1e-9)
+    finally:
+        hmm.set_option("emit_mode", -1)
+    hb = b.hap_bases.copy()
+    hb[5], hb[int(b.hap_offsets[1]) + 9] = ord("a"), ord("R")  # raw bytes are compared (Log10PairHMM.java:156): these match nothing here
+    odd = Batch(b.read_bases, b.read_quals, b.ins_gop, b.del_gop, b.gcp, b.read_offsets, hb, b.hap_offsets)
+    assert_parity(hmm.compute_batch(odd), ref(oracle, odd), tol=1e-9)
 
 
 def test_long_reads_among_ordinary_ones(hmm, oracle):
