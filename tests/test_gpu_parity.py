@@ -253,6 +253,27 @@ def test_long_read_workgroups_of_every_size(hmm, oracle, num_haps):
     assert_parity(hmm.compute_batch(odd), ref(oracle, odd), tol=1e-9)
 
 
+def test_long_read_against_short_haplotypes(hmm, oracle):
+    """Haplotypes shorter than one block of 64 columns, of exactly one, and a little more, against a read of four
+    chunks of rows: the hand-off between chunks when a block is cut short.  Cheap gaps (open and continuation quality 1)
+    keep the thousand insertions such a pair needs finite."""
+    rng = np.random.default_rng(75)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    n = 1700
+    hap = acgt[rng.integers(0, 4, 200)]
+    read = np.resize(hap, n).copy()
+    ones = np.ones(n, np.uint8)
+    b = pack([(read, rng.integers(10, 40, n), ones, ones, ones)], [hap[:1], hap[:5], hap[:63], hap[:64], hap[:65], hap[:130], hap])
+    want = ref(oracle, b, 1)
+    assert np.isfinite(want).all()
+    assert_parity(hmm.compute_batch(b), want, tol=1e-9)
+    hmm.set_option("emit_mode", 0)
+    try:
+        assert_parity(hmm.compute_batch(b), want, tol=1e-9)
+    finally:
+        hmm.set_option("emit_mode", -1)
+
+
 def test_long_reads_among_ordinary_ones(hmm, oracle):
     """Reads for the long-read pass, ordinary reads, a read of exactly 1022 bases (the longest a wave-group takes) and
     a zero-length read in one region, next to a region of ordinary reads and one that holds a long read only: every
