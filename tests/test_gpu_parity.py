@@ -274,6 +274,49 @@ def test_long_read_against_short_haplotypes(hmm, oracle):
         hmm.set_option("emit_mode", -1)
 
 
+def test_long_reads_through_the_other_entry_points(oracle):
+    """A region with two reads for the long-read pass among ordinary ones through the per-pair call, BatchPairHMM,
+    a resident batch computed twice, and the region-level hook followed by computeLikelihoods: the same likelihoods as
+    from compute_batch, which the oracle vouches for."""
+    rng = np.random.default_rng(76)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    hap = acgt[rng.integers(0, 4, 1500)]
+    lens = [140, 1300, 151, 1023, 90]
+    recs = []
+    for n in lens:
+        gop = rng.integers(30, 50, n).astype(np.uint8)
+        recs.append((_near_copy(rng, hap, int(rng.integers(0, 100)), n), rng.integers(10, 40, n).astype(np.uint8), gop, gop[::-1].copy(),
+                     np.full(n, 10, np.uint8)))
+    haps = [hap, hap[:1450], hap[25:]]
+    b = pack(recs, haps)
+    want = ref(oracle, b, 1)
+    assert np.isfinite(want).all()
+    h = pairhmm.HipLoglessPairHMM(0)
+    try:
+        assert_parity(h.compute_batch(b), want)
+        h.initialize(1400, 1600)
+        for r in (1, 3):
+            lk = h.computeReadLikelihoodGivenHaplotypeLog10(bytes(haps[1]), bytes(recs[r][0]), *recs[r][1:])
+            assert abs(lk - want[r, 1]) <= 1e-9
+        for rd in recs:
+            h.batchAdd([bytes(x) for x in haps], bytes(rd[0]), *rd[1:])
+        assert_parity(h.batchGetResult().reshape(want.shape), want)
+        res = h.upload([b, b])
+        try:
+            for _ in range(2):
+                res.compute()
+                for got in res.download():
+                    assert_parity(got, want)
+        finally:
+            res.free()
+        h.initialize_region_batches([b], 1400, 1600)
+        assert_parity(h.compute_batch(b), want)
+        assert h.stats()["region_hits"] >= 1
+        h.finalizeRegion()
+    finally:
+        h.close()
+
+
 def test_long_reads_among_ordinary_ones(hmm, oracle):
     """Reads for the long-read pass, ordinary reads, a read of exactly 1022 bases (the longest a wave-group takes) and
     a zero-length read in one region, next to a region of ordinary reads and one that holds a long read only: every
