@@ -988,6 +988,7 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
         DeviceBatch Lg = B;
         Lg.long_boundary = R->d_long_boundary.as<double>();
         Lg.long_boundary_stride = stride;
+        Lg.long_withhold_progress = h->debug_long_stall ? 1 : 0;
         // Emission terms from a per-wave LDS table (a quarter faster per wave, but 20 KiB of LDS a wave: six waves on a CU
         // instead of eight) when every pair of the call is resident at once even so; byte compares otherwise.
         bool table = R->haps_acgtn_only && h->emit_mode != 0 && long_table_fits(waves_per_block);
@@ -1914,6 +1915,7 @@ int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value) try
             if (int rc = gatk_pairhmm_set_option(c, name, value)) return rc;
     if (n == "multi_min_pairs") h->multi_min_pairs = std::max<int64_t>(0, static_cast<int64_t>(value));
     else if (n == "fp32_threshold") h->fp32_threshold = static_cast<float>(value);
+    else if (n == "debug_long_stall") h->debug_long_stall = value != 0;
     else if (n == "force_rows_per_lane") h->force_rows_per_lane = static_cast<int>(value);
     else if (n == "force_fp64") h->force_fp64 = value != 0;
     else if (n == "emit_mode") h->emit_mode = static_cast<int>(value);

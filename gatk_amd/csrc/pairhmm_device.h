@@ -158,7 +158,8 @@ struct DeviceBatch {
     const RerunPair* long_pairs;   // [num_long_pairs]
     int32_t num_long_pairs;
     int32_t long_boundary_stride;  // entries of one boundary row (the launch's longest haplotype, rounded up)
-    double* long_boundary;         // [waves of the launch][2 rows][long_boundary_stride][2]: what a chunk of rows hands the chunk below it, per column
+    int32_t long_withhold_progress;  // test hook: the first chunk of every pair never says how far it has come, so that the chunk below gives up waiting
+    double* long_boundary;         // [workgroups of the launch][waves of a workgroup + 1 rows][long_boundary_stride][2]: what a chunk of rows hands the chunk below it, per column
     int32_t num_region_descs;
     int32_t num_tasks;             // this launch's work items
     const double* err_prob;        // [256]

@@ -288,6 +288,7 @@ struct gatk_pairhmm {
     pairhmm_host::PinnedBuf done_flag;                               // that flag (one word of pinned host memory)
     pairhmm_host::PinnedBuf signal_out;                              // and where such a result lands (coherent pinned memory)
     unsigned done_seq = 0;                             // value the next such download stores there
+    bool debug_long_stall = false;  // test hook: the long-read pass withholds a chunk's progress, so that the wait for it runs into its limit
     int stream_run_divisor = 2;  // a haplotype run of the stream pass is the items still to hand out over this many times the wave slots
     std::vector<uint8_t> group_rows_table;  // rows per lane by longest read of a wave-group when only some values are allowed (empty: all are)
     int64_t per_group_factor = 32;  // calls with at least this many pairs per wave slot choose rows per lane per wave-group

@@ -1557,8 +1557,8 @@ __device__ __forceinline__ double run_long_chunk(const DeviceBatch& B, const Rer
         v = double2{0.0, 0.0};
         if (!from_above || s0 >= H) return;  // wave-uniform
         const int need = tag_in + min(s0 + kWave, H);
-        for (int spins = 0; __hip_atomic_load(progress + row_in, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need; ++spins) {
-            if (spins > kLongSpinLimit) { stalled = true; break; }
+        for (int spins = 0; !stalled && __hip_atomic_load(progress + row_in, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need; ++spins) {
+            if (spins > kLongSpinLimit) stalled = true;  // once per wave: no later wait of this wave spins again
             __builtin_amdgcn_s_sleep(8);
         }
         const int j = s0 + lane;
@@ -1603,7 +1603,8 @@ __device__ __forceinline__ double run_long_chunk(const DeviceBatch& B, const Rer
         }
         if (to_below) {  // the last lane has finished the columns up to block_end - 64: its stores first, then the count
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (lane == 0) __hip_atomic_store(progress + row_out, tag_out + min(max(block_end - (kWave - 1), 0), H), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0 && !(B.long_withhold_progress && chunk == 0))
+                __hip_atomic_store(progress + row_out, tag_out + min(max(block_end - (kWave - 1), 0), H), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     T total = 0.0;
