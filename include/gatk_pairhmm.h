@@ -283,7 +283,10 @@ int gatk_pairhmm_device_count(int32_t* count);
  *   "stream_lds_floor"    least bytes of LDS a wave of the fp32 stream pass asks for; a larger value lowers the
  *                         number of waves a CU holds (occupancy experiments).
  *   "multi_min_pairs"     multi-device handles only, default 8192: a call with fewer pairs goes to one engine on the
- *                         calling thread. */
+ *                         calling thread.
+ *   "debug_long_stall"    tests only: 1 = in the pass for reads of more than 1022 bases the first 512 rows of every
+ *                         pair never announce their progress, so that the wavefront behind them runs into the limit of
+ *                         its wait (about half a second) and the call returns GATK_PAIRHMM_DEVICE_ERROR. */
 int gatk_pairhmm_set_option(gatk_pairhmm* h, const char* name, double value);
 
 /*
