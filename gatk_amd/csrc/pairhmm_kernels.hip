@@ -1603,7 +1603,7 @@ __device__ __forceinline__ double run_long_chunk(const DeviceBatch& B, const Rer
         }
         if (to_below) {  // the last lane has finished the columns up to block_end - 64: its stores first, then the count
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (lane == 0 && !(B.long_withhold_progress && chunk == 0))
+            if (lane == kWave - 1 && !(B.long_withhold_progress && chunk == 0))  // the lane whose stores it vouches for
                 __hip_atomic_store(progress + row_out, tag_out + min(max(block_end - (kWave - 1), 0), H), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
