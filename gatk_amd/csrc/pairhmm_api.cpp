@@ -853,6 +853,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     R->long_hap_max = long_hap_max;
     R->long_read_max = long_read_max;
     R->haps_acgtn_only = !any_hap_other;
+    R->haps_have_n = any_hap_n;
     R->hap_stream_entries = scur + kStreamBackPad;
     if (R->hap_stream_entries >= (size_t{1} << 31)) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, "more than 2^31 haplotype bases in one call");
     const double t_planned = now_ms();
@@ -989,14 +990,19 @@ int enqueue_compute(gatk_pairhmm* h, gatk_pairhmm_resident* R) {
         Lg.long_boundary = R->d_long_boundary.as<double>();
         Lg.long_boundary_stride = stride;
         Lg.long_withhold_progress = h->debug_long_stall ? 1 : 0;
-        // Emission terms from a per-wave LDS table (a quarter faster per wave, but 20 KiB of LDS a wave: six waves on a CU
-        // instead of eight) when every pair of the call is resident at once even so; byte compares otherwise.
-        bool table = R->haps_acgtn_only && h->emit_mode != 0 && long_table_fits(waves_per_block);
-        if (table) {
-            const int per_cu = std::min((160 * 1024) / long_lds_bytes(waves_per_block, R->long_hap_max, true), 8 / waves_per_block);
-            table = R->num_long_pairs <= per_cu * (simds / 4);
+        // Emission terms from a per-wave LDS table (a quarter faster per wave, but 16 KiB of LDS a wave, 20 with a column
+        // for 'N') when a CU holds as many waves with it as without, or when every pair of the call is resident at once
+        // even so; byte compares otherwise.
+        int table_codes = 0;
+        if (R->haps_acgtn_only && h->emit_mode != 0 && long_table_fits(waves_per_block)) {
+            const int codes = R->haps_have_n ? 5 : 4;
+            const int lds_cu = 160 * 1024, most = 8 / waves_per_block;  // two waves a SIMD by registers
+            const int with_table = std::min(lds_cu / long_lds_bytes(waves_per_block, R->long_hap_max, codes), most);
+            const int without = std::min(lds_cu / long_lds_bytes(waves_per_block, R->long_hap_max, 0), most);
+            if (with_table >= without || R->num_long_pairs <= with_table * (simds / 4)) table_codes = codes;
         }
-        HIP_TRY(launch_long(Lg, blocks, waves_per_block, R->long_hap_max, table, s));
+        Lg.long_table_codes = table_codes;
+        HIP_TRY(launch_long(Lg, blocks, waves_per_block, R->long_hap_max, s));
     }
     if (timing) HIP_TRY(hipEventRecord(ev[1], s));
     auto bucket_args = [&](size_t bi, int mode) {

@@ -158,6 +158,7 @@ struct DeviceBatch {
     const RerunPair* long_pairs;   // [num_long_pairs]
     int32_t num_long_pairs;
     int32_t long_boundary_stride;  // entries of one boundary row (the launch's longest haplotype, rounded up)
+    int32_t long_table_codes;      // 0: the long-read pass compares bytes; 4 or 5: base codes of its emission table (5: with 'N')
     int32_t long_withhold_progress;  // test hook: the first chunk of every pair never says how far it has come, so that the chunk below gives up waiting
     double* long_boundary;         // [workgroups of the launch][waves of a workgroup + 1 rows][long_boundary_stride][2]: what a chunk of rows hands the chunk below it, per column
     int32_t num_region_descs;

@@ -39,9 +39,9 @@ int stream_lds_bytes_per_wave(int rows_per_lane, int emit_mode);
 hipError_t launch_stream(const DeviceBatch& B, int rows_per_lane, int emit_mode, hipStream_t stream);
 hipError_t launch_finish_stream(const DeviceBatch& B, hipStream_t stream);
 hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int waves, hipStream_t stream);
-hipError_t launch_long(const DeviceBatch& B, int blocks, int waves_per_block, int max_hap_len, bool table, hipStream_t stream);
+hipError_t launch_long(const DeviceBatch& B, int blocks, int waves_per_block, int max_hap_len, hipStream_t stream);
 bool long_table_fits(int waves_per_block);
-int long_lds_bytes(int waves_per_block, int max_hap_len, bool table);
+int long_lds_bytes(int waves_per_block, int max_hap_len, int table_codes);
 hipError_t launch_normalize_reads(const DeviceBatch& B, const int32_t* reference_allele_index, int best_to_zero, double cap, hipStream_t stream);
 hipError_t launch_flag_poorly_modelled_reads(const DeviceBatch& B, double maximum_error_per_base, uint8_t* flags, hipStream_t stream);
 hipError_t launch_marginalize_reads(const DeviceBatch& B, const int32_t* old_to_new, const int64_t* new_base, const int32_t* new_count,
@@ -239,6 +239,7 @@ struct gatk_pairhmm_resident {
     int long_hap_max = 0;                  // longest haplotype among them
     int long_read_max = 0;                 // longest of those reads
     bool haps_acgtn_only = false;          // no haplotype of the call holds a byte other than A, C, G, T, N
+    bool haps_have_n = false;              // one of them holds an N
     size_t hap_stream_entries = 0;
     std::vector<int32_t> region_reads, region_haps;     // per region of the call (0 haplotypes when it has no reads)
     std::vector<int32_t> region_read_begin, region_hap_begin;  // global index of a region's first read / haplotype

@@ -1435,11 +1435,14 @@ constexpr int kLongSpinLimit = 1 << 21;      // waits of a quarter of a microsec
 
 // stage: this wave's kLongStageBytes of LDS; progress: the workgroup's counters; hb: the haplotype in LDS, its bytes or,
 // with a table, its base codes; table: this wave's emission table in LDS, as the fp64 pair pass lays it out
-// ([row pair][base code][lane][2] doubles), written anew for every chunk.
-template <bool kTable>
+// ([row pair][base code][lane][2] doubles; `codes` base codes: A C T G, and N when a haplotype of the call holds one),
+// written anew for every chunk.
+template <int kCodes>  // 0: compare bytes; 4 or 5: base codes of the table
 __device__ __forceinline__ double run_long_chunk(const DeviceBatch& B, const RerunPair pr, const int chunk, const int num_waves,
                                                  double* boundary, double2* stage, int* progress, const uint8_t* hb, unsigned char* table,
                                                  const int lane, bool& stalled) {
+    constexpr bool kTable = kCodes != 0;
+    constexpr int codes = kCodes;
     using T = double;
     constexpr int K = kLongRows;
     const int ro = B.read_off[pr.read_idx];
@@ -1513,7 +1516,7 @@ __device__ __forceinline__ double run_long_chunk(const DeviceBatch& B, const Rer
         if constexpr (kTable) {
 #pragma unroll
             for (int cd = 0; cd < kPairCodes; ++cd)  // a haplotype 'N' matches every row, a read 'N' (q = p) every column
-                tbl[(((r >> 1) * kPairCodes + cd) * kWave + lane) * 2 + (r & 1)] = (xb == letters[cd] || cd == 4) ? p : q;
+                if (cd < codes) tbl[(((r >> 1) * codes + cd) * kWave + lane) * 2 + (r & 1)] = (xb == letters[cd] || cd == 4) ? p : q;
         } else {
             P[r] = p;
             Q[r] = q;
@@ -1538,7 +1541,7 @@ __device__ __forceinline__ double run_long_chunk(const DeviceBatch& B, const Rer
         if constexpr (kTable) {
 #pragma unroll
             for (int g2 = 0; g2 < K / 2; ++g2) {
-                const double2 v = *reinterpret_cast<const double2*>(tbl_lane + y * kLutCodeStride + g2 * kPairCodes * kLutCodeStride);
+                const double2 v = *reinterpret_cast<const double2*>(tbl_lane + y * kLutCodeStride + g2 * codes * kLutCodeStride);
                 prior[2 * g2] = v.x;
                 prior[2 * g2 + 1] = v.y;
             }
@@ -1613,15 +1616,16 @@ __device__ __forceinline__ double run_long_chunk(const DeviceBatch& B, const Rer
 }
 
 // Workgroups of 1 to kLongMaxWaves waves, a pair at a time; a workgroup owns waves + 1 boundary rows.
-// Dynamic LDS: [waves x kLongStageBytes][kLongProgressBytes][with a table: waves x kLongTableBytes][the longest
+// Dynamic LDS: [waves x kLongStageBytes][kLongProgressBytes][with a table: waves x long_table_bytes][the longest
 // haplotype's bytes, rounded up to 16].  kTable: emission terms from a per-wave table instead of comparing bytes, a third
-// fewer vector instructions per step; for launches of one or two waves per workgroup (the table is 20 KiB a wave)
-// whose haplotypes hold A, C, G, T and N only.
-constexpr int kLongTableBytes = pair_table_bytes(kLongRows);
+// fewer vector instructions per step; for launches of one or two waves per workgroup (the table is 16 KiB a wave, 20
+// with a column for 'N') whose haplotypes hold A, C, G, T and N only.
+constexpr int long_table_bytes(int codes) { return (kLongRows / 2) * codes * kLutCodeStride; }
 constexpr int kLongTableMaxWaves = 2;
 
-template <bool kTable>
+template <int kCodes>
 __global__ void __launch_bounds__(kWave* kLongMaxWaves) fwd_long(const DeviceBatch B) {
+    constexpr bool kTable = kCodes != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int num_waves = static_cast<int>(blockDim.x) >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
@@ -1630,7 +1634,8 @@ __global__ void __launch_bounds__(kWave* kLongMaxWaves) fwd_long(const DeviceBat
     double2* const stage = reinterpret_cast<double2*>(lds + wave * kLongStageBytes);
     int* const progress = reinterpret_cast<int*>(lds + num_waves * kLongStageBytes);
     unsigned char* const tables = lds + num_waves * kLongStageBytes + kLongProgressBytes;
-    uint8_t* const hb = tables + (kTable ? num_waves * kLongTableBytes : 0);
+    constexpr int table_bytes = kTable ? long_table_bytes(kCodes) : 0;
+    uint8_t* const hb = tables + num_waves * table_bytes;
     bool stalled = false;
     for (int p = blockIdx.x; p < B.num_long_pairs; p += gridDim.x) {
         const RerunPair pr = B.long_pairs[p];
@@ -1658,7 +1663,7 @@ __global__ void __launch_bounds__(kWave* kLongMaxWaves) fwd_long(const DeviceBat
         if (threadIdx.x <= static_cast<unsigned>(num_waves)) progress[threadIdx.x] = 0;
         __syncthreads();
         for (int chunk = wave; chunk < chunks; chunk += num_waves) {
-            const double total = run_long_chunk<kTable>(B, pr, chunk, num_waves, boundary, stage, progress, hb, tables + wave * kLongTableBytes, lane, stalled);
+            const double total = run_long_chunk<kCodes>(B, pr, chunk, num_waves, boundary, stage, progress, hb, tables + wave * table_bytes, lane, stalled);
             if (chunk == chunks - 1 && lane == ((total_lanes - 1) & (kWave - 1)))
                 B.out[B.read_out_base[pr.read_idx] + pr.hap_local] = ::log10(total) - Scale<double>::kExp2 * 0.30102999566398119521;
         }
@@ -1926,16 +1931,21 @@ hipError_t launch_pairs(const DeviceBatch& B, int rows_per_lane, int waves, hipS
 // Enqueue the long-read pass (B.long_pairs / num_long_pairs / long_boundary / long_boundary_stride set); waves: one-wave blocks.
 bool long_table_fits(int waves_per_block) { return waves_per_block <= kLongTableMaxWaves; }
 
-int long_lds_bytes(int waves_per_block, int max_hap_len, bool table) {
-    return waves_per_block * kLongStageBytes + kLongProgressBytes + (table ? waves_per_block * kLongTableBytes : 0) + ((max_hap_len + 15) & ~15);
+// table_codes: 0 = no table, 4 or 5 = a table with that many base codes
+int long_lds_bytes(int waves_per_block, int max_hap_len, int table_codes) {
+    return waves_per_block * kLongStageBytes + kLongProgressBytes + (table_codes ? waves_per_block * long_table_bytes(table_codes) : 0) + ((max_hap_len + 15) & ~15);
 }
 
-hipError_t launch_long(const DeviceBatch& B, int blocks, int waves_per_block, int max_hap_len, bool table, hipStream_t stream) {
+hipError_t launch_long(const DeviceBatch& B, int blocks, int waves_per_block, int max_hap_len, hipStream_t stream) {
     if (blocks <= 0 || B.num_long_pairs <= 0) return hipSuccess;
-    if (waves_per_block < 1 || waves_per_block > kLongMaxWaves || (table && !long_table_fits(waves_per_block))) return hipErrorInvalidValue;
-    const size_t lds = static_cast<size_t>(long_lds_bytes(waves_per_block, max_hap_len, table));
-    if (table) hipLaunchKernelGGL(fwd_long<true>, dim3(blocks), dim3(kWave * waves_per_block), lds, stream, B);
-    else hipLaunchKernelGGL(fwd_long<false>, dim3(blocks), dim3(kWave * waves_per_block), lds, stream, B);
+    const int codes = B.long_table_codes;
+    if (waves_per_block < 1 || waves_per_block > kLongMaxWaves || (codes != 0 && codes != 4 && codes != 5) || (codes && !long_table_fits(waves_per_block)))
+        return hipErrorInvalidValue;
+    const size_t lds = static_cast<size_t>(long_lds_bytes(waves_per_block, max_hap_len, codes));
+    const dim3 grid(blocks), block(kWave * waves_per_block);
+    if (codes == 5) hipLaunchKernelGGL(fwd_long<5>, grid, block, lds, stream, B);
+    else if (codes == 4) hipLaunchKernelGGL(fwd_long<4>, grid, block, lds, stream, B);
+    else hipLaunchKernelGGL(fwd_long<0>, grid, block, lds, stream, B);
     return hipGetLastError();
 }
 
