@@ -214,6 +214,19 @@ int choose_group_rows_per_lane(int longest) {
     return table[longest];
 }
 
+// What can be said about a region without walking its reads: counts and pointers.  After it the region's offset
+// tables may be read at their two ends.
+int check_region_arrays(const gatk_pairhmm_batch& b, int k) {
+    const auto where = [k] { return " (region " + std::to_string(k) + ")"; };  // built only for a failure
+    if (b.num_reads < 0 || b.num_haps < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("negative read or haplotype count") + where());
+    if (b.num_reads == 0) return GATK_PAIRHMM_OK;  // PairHMM.java:193
+    if (!b.read_offsets || !b.read_bases || !b.read_quals)  // insertion / deletion / GCP arrays may be null: defaults
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("readBases cannot be null") + where());
+    if (b.num_haps > 0 && (!b.hap_offsets || !b.hap_bases))
+        return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("haplotypeBases cannot be null") + where());
+    return GATK_PAIRHMM_OK;
+}
+
 int check_region(const gatk_pairhmm_batch& b, int k, int* read_max_out, int* hap_max_out) {
     const auto where = [k] { return " (region " + std::to_string(k) + ")"; };  // built only for a failure
     if (b.num_reads < 0 || b.num_haps < 0) return fail(GATK_PAIRHMM_ILLEGAL_ARGUMENT, std::string("negative read or haplotype count") + where());
@@ -384,6 +397,7 @@ int64_t pipeline_weight(const gatk_pairhmm_batch& b, int64_t ref_cells) {
 //   * A smaller one that has the device to itself: two halves of at least min_pairs, so that the planning of the
 //     second and the copy back of the first hide behind kernels; below two min_pairs, one part.
 // No cut leaves less than half a part behind it.
+constexpr int kCheckByPartFromRegions = 64;  // calls of at least this many regions are checked as their parts are planned
 struct CutRules { int64_t pipeline_pairs, min_pairs, mid_ramp_min; bool ramp; int ramp_steps; bool device_is_shared; };
 std::vector<int> part_cuts(const std::vector<int64_t>& weights, const CutRules& rules) {
     const int n = static_cast<int>(weights.size());
@@ -422,7 +436,7 @@ int plan_and_upload(gatk_pairhmm* h, gatk_pairhmm_resident* R, int num_regions, 
     if (!checked)
         for (int k = 0; k < num_regions; ++k) {
             int read_max = 0, hap_max = 0;
-            if (int rc = check_region(regions[k], k, &read_max, &hap_max)) return rc;
+            if (int rc = check_region(regions[k], R->region_label_base + k, &read_max, &hap_max)) return rc;
             note_call_maxima(h, regions[k], read_max, hap_max);
         }
 
@@ -1381,12 +1395,22 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
 #ifdef PAIRHMM_CALL_CLOCKS
     const auto call_t0 = std::chrono::steady_clock::now();
 #endif
-    if (!checked)
+    // A call of many regions is checked part by part, as each part is planned: walking the offset tables of two
+    // thousand regions first would keep the device waiting for a fifth of a millisecond, on cache lines the planner
+    // then has to fetch again.  Only counts and pointers are looked at beforehand (what the cut rules read).
+    bool checked_by_part = false;
+    if (!checked) {
+        checked_by_part = num_regions >= kCheckByPartFromRegions && h->pipeline_pairs > 0;
         for (int k = 0; k < num_regions; ++k) {
+            if (checked_by_part) {
+                if (int rc = check_region_arrays(regions[k], k)) return rc;
+                continue;
+            }
             int read_max = 0, hap_max = 0;
             if (int rc = check_region(regions[k], k, &read_max, &hap_max)) return rc;
             note_call_maxima(h, regions[k], read_max, hap_max);
         }
+    }
     CALL_CLOCK("checked");
     const RegionCallCount in_flight(h->device);
     // How much of a part a region takes: its pairs, and for a region of long reads against long haplotypes (more
@@ -1406,6 +1430,14 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
         for (int k = 0; k < num_regions && !any_large; ++k)
             any_large = regions[k].num_reads > 1 && regions[k].num_haps > 0 && weight_of(regions[k]) >= 2 * h->pipeline_pairs;
         if (any_large) {
+            if (checked_by_part) {  // the pieces are not the caller's regions: check those while they are still at hand
+                for (int k = 0; k < num_regions; ++k) {
+                    int read_max = 0, hap_max = 0;
+                    if (int rc = check_region(regions[k], k, &read_max, &hap_max)) return rc;
+                    note_call_maxima(h, regions[k], read_max, hap_max);
+                }
+                checked_by_part = false;
+            }
             for (int k = 0; k < num_regions; ++k) {
                 const gatk_pairhmm_batch& b = regions[k];
                 const int n_pieces = static_cast<int>(std::min<int64_t>(std::max<int64_t>(weight_of(b) / h->pipeline_pairs, 1), std::max(b.num_reads, 1)));
@@ -1440,7 +1472,7 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
         return fail_input_error(h, rc, at.first, at.second + h->error_read, false);
     };
     if (cuts.size() <= 2) {
-        if (int rc = plan_and_upload(h, &h->scratch, num_regions, regions, true)) return rc;
+        if (int rc = plan_and_upload(h, &h->scratch, num_regions, regions, !checked_by_part)) return rc;
         if (h->scratch.total_pairs == 0) { h->stats = gatk_pairhmm_stats{}; return GATK_PAIRHMM_OK; }
         if (int rc = enqueue_compute(h, &h->scratch)) return rc;
         return in_callers_terms(download_into(h, &h->scratch, likelihoods));
@@ -1480,7 +1512,7 @@ int pairhmm_host::compute_regions_single(gatk_pairhmm* h, int32_t num_regions, c
         gatk_pairhmm_resident* R = slot[p % depth];
         R->region_label_base = cuts[p];
         CALL_CLOCK("part begins");
-        rc = plan_and_upload(h, R, cuts[p + 1] - cuts[p], regions + cuts[p], true);
+        rc = plan_and_upload(h, R, cuts[p + 1] - cuts[p], regions + cuts[p], !checked_by_part);
         CALL_CLOCK("  planned, upload enqueued");
         if (rc == GATK_PAIRHMM_OK && R->total_pairs > 0) rc = enqueue_compute(h, R);
         CALL_CLOCK("  kernels enqueued");

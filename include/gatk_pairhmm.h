@@ -185,7 +185,9 @@ int gatk_pairhmm_compute_likelihoods_ptrs(gatk_pairhmm* h, int32_t num_reads, in
 
 /* Many computeLikelihoods calls (regions x samples) in one device pass: what the concurrent
  * map threads of the reference (nanoScheduler/NanoScheduler.java:112) would each submit, batched
- * so that small regions fill the GPU.  likelihoods[k] receives region k's read-major array. */
+ * so that small regions fill the GPU.  likelihoods[k] receives region k's read-major array.
+ * When the call fails (a malformed region, an input error in a read), the arrays of regions in front of the
+ * failing one may already hold their results: a call of many regions is checked and scored part by part. */
 int gatk_pairhmm_compute_regions(gatk_pairhmm* h, int32_t num_regions, const gatk_pairhmm_batch* regions,
                                  double* const* likelihoods);
 

@@ -126,6 +126,22 @@ def test_multi_device_handle_options_errors_and_single_pair(multi, oracle, hc_re
     assert abs(lk - ref(oracle, b)[0, 0]) <= TOL
 
 
+def test_a_malformed_region_late_in_a_large_call_is_named(hmm, oracle, hc_regions):
+    """A call of many regions is checked part by part while the parts before are already on the device: a region
+    whose offsets decrease, four hundred regions in, is still reported under its own index, as is one with a
+    zero-length haplotype in the last part; nothing is left in flight, and the next call is right."""
+    worse = synth.make_batch(4, 2, 20, 50, seed=3)
+    worse.read_offsets = worse.read_offsets.copy(); worse.read_offsets[2] = worse.read_offsets[1] - 1
+    with pytest.raises(pairhmm.IllegalArgumentException, match=r"read offsets must not decrease \(region 400\)"):
+        hmm.compute_regions(hc_regions[:400] + [worse] + hc_regions[400:500])
+    empty_hap = synth.make_batch(4, 2, 20, 50, seed=4)
+    empty_hap.hap_offsets = empty_hap.hap_offsets.copy(); empty_hap.hap_offsets[1] = empty_hap.hap_offsets[0]
+    with pytest.raises(pairhmm.IllegalArgumentException, match=r"zero-length haplotype.*\(region 1199\)"):
+        hmm.compute_regions(hc_regions[:1199] + [empty_hap])
+    got = hmm.compute_regions(hc_regions[:80])
+    check_against_oracle(oracle, hc_regions[:80], got, [0, 41, 79])
+
+
 def test_reads_for_the_long_read_pass_on_the_multi_device_handle(hmm, multi, oracle, hc_regions):
     """Reads of more than 1022 bases in regions that go whole to one engine, and in one large region that is cut by
     read ranges between the engines: each engine runs its own long-read launch on its share."""
